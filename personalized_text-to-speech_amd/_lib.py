@@ -1,0 +1,85 @@
+"""ctypes binding of libvitsmi.so (the C ABI declared in include/vitsmi.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (``make -C csrc``) and is the ONLY
+implementation of the hot ops: there is no CPU or eager fallback behind it.  ``lib()`` raises
+``RuntimeError`` if the shared object is missing or an expected symbol is not exported.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvitsmi.so")
+ABI_VERSION = 1
+
+c_int = ctypes.c_int
+c_void_p = ctypes.c_void_p
+c_float = ctypes.c_float
+c_size_t = ctypes.c_size_t
+
+# name -> (restype, argtypes); kept in lock-step with include/vitsmi.h (tests/test_abi.py checks
+# that every function declared in the header is listed here and exported by the .so).
+SIGNATURES = {
+    "vits_abi_version": (c_int, []),
+    "vits_last_error": (ctypes.c_char_p, []),
+    "vits_mas_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile csrc/*.hip for gfx950 into lib/libvitsmi.so (hipcc cross-compiles without a GPU)."""
+    res = subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j8"], capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("building libvitsmi.so failed:\n" + res.stdout[-4000:] + res.stderr[-4000:])
+    if verbose:
+        print(res.stdout[-2000:])
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`. "
+                "The HIP kernels have no fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError as e:
+                raise RuntimeError(f"libvitsmi.so does not export {name}: rebuild it") from e
+            fn.restype = res
+            fn.argtypes = args
+        got = handle.vits_abi_version()
+        if got != ABI_VERSION:
+            raise RuntimeError(f"libvitsmi.so ABI {got} != binding ABI {ABI_VERSION}: rebuild it")
+        _lib = handle
+    return _lib
+
+
+class VitsKernelError(RuntimeError):
+    pass
+
+
+_CODES = {-1: "VITS_E_BADARG", -2: "VITS_E_UNSUPPORTED", -3: "VITS_E_LAUNCH"}
+
+
+def check(rc, what):
+    if rc != 0:
+        detail = lib().vits_last_error().decode() if rc == -3 else ""
+        raise VitsKernelError(f"{what}: {_CODES.get(rc, rc)} {detail}")
+
+
+def stream_ptr():
+    """The hipStream_t of torch's current stream, as an integer for the C ABI."""
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("this op runs only through the HIP kernels of libvitsmi.so: tensors must be on the GPU")

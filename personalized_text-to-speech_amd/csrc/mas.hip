@@ -1,0 +1,231 @@
+// Monotonic alignment search on gfx950: maximum-path DP + backtrack, one workgroup per item.
+//
+// Replaces reference monotonic_align/core.pyx:5-42 (maximum_path_each / maximum_path_c) and the
+// host round trip of monotonic_align/__init__.py:6-19.
+//
+// Work split inside a workgroup (512 threads = 8 waves), software-pipelined over blocks of R=16
+// rows (frames) with one workgroup barrier per block:
+//   waves 1..7  loaders: copy row block k+2 of neg_cent from HBM into a 3-slot LDS ring
+//               (coalesced dword loads, one column per thread), and zero-fill a slice of the
+//               item's [t_t, t_s] output (write-only, as large as the input) — so both HBM
+//               streams run underneath the DP.
+//   wave 0      the DP on block k, out of LDS.  Lane l owns the E consecutive text columns
+//               x = l*E .. l*E+E-1 and keeps the previous DP row in registers; the left
+//               neighbour of a lane's first column arrives by one DPP wave-shift per row.
+//               Only the 1-bit back-pointer (value[y-1][x] < value[y-1][x-1]) of each cell is
+//               kept: 32 rows per lane register, flushed to an LDS bit matrix dir[y/32][x].
+//   wave 0      backtrack over the bit matrix; all waves then scatter the t_y ones.
+//
+// Why the result is bit-identical to the reference: every in-band cell is neg_cent[y][x] plus the
+// larger of two previously computed cells — one fp32 add per cell, no reassociation.  In-band
+// cells only ever read in-band cells (or the two boundary constants), so whatever is computed
+// outside the band [max(0,t_x+y-t_y), min(t_x,y+1)) never reaches a value the backtrack reads.
+#include "common.h"
+
+namespace {
+
+constexpr float kNeg = -1e9f;            // max_neg_val of core.pyx:7 (exactly representable)
+constexpr int kThreads = 512;
+constexpr int kLoaders = kThreads - 64;
+constexpr int R = 16;                    // rows per pipeline block
+constexpr int kSlots = 3;                // LDS ring depth (blocks)
+
+__device__ __forceinline__ float wave_shr1(float src, float fill) {
+  // lane l <- lane l-1; lane 0 <- fill   (DPP wave_shr:1, bound_ctrl off => keeps `old`)
+  int r = __builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(src), 0x138, 0xf, 0xf, false);
+  return __int_as_float(r);
+}
+
+// E consecutive floats from LDS; the address is 4*min(E,4)-byte aligned by construction.
+template <int E>
+__device__ __forceinline__ void read_chunk(float (&dst)[E], const float* p) {
+  if constexpr (E == 1) {
+    dst[0] = p[0];
+  } else if constexpr (E == 2) {
+    const float2 v = *reinterpret_cast<const float2*>(p);
+    dst[0] = v.x; dst[1] = v.y;
+  } else {
+#pragma unroll
+    for (int q = 0; q < E / 4; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(p + 4 * q);
+      dst[4 * q + 0] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w;
+    }
+  }
+}
+
+__host__ __device__ inline int ring_stride(int T_s, int E) {
+  // floats per staged row: 16-byte aligned rows, and room for the last lane's full E-chunk
+  int w = ((T_s + E - 1) / E) * E;
+  return (w + 3) & ~3;
+}
+
+// E columns per lane (t_s <= 64*E).
+template <int E>
+__global__ __launch_bounds__(kThreads) void mas_kernel(const float* __restrict__ neg_cent,
+                                                       uint32_t* __restrict__ path,
+                                                       const int* __restrict__ t_ys,
+                                                       const int* __restrict__ t_xs,
+                                                       int T_t, int T_s,
+                                                       uint32_t one_bits, int* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  constexpr int TSP = vits::kWave * E;           // padded row length of the bit matrix
+
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int t_y = t_ys[b];
+  const int t_x = t_xs[b];
+  const bool valid = (t_x >= 1) && (t_x <= t_y) && (t_y <= T_t) && (t_x <= T_s);
+  const size_t item_elems = (size_t)T_t * T_s;
+  const size_t item_off = (size_t)b * item_elems;
+
+  const int nblk32 = (T_t + 31) >> 5;
+  const int rs = ring_stride(T_s, E);
+  uint32_t* dir = smem;                                          // [nblk32][TSP] back-pointer bits
+  int* idxs = reinterpret_cast<int*>(dir + (size_t)nblk32 * TSP); // [T_t] path column per row
+  float* ring = reinterpret_cast<float*>(idxs + ((T_t + 3) & ~3)); // [kSlots][R][rs] (+E slack)
+
+  const int n_blk = valid ? (t_y + R - 1) / R : 0;               // pipeline blocks of R rows
+  const float* src = neg_cent + item_off;
+
+  // zero-fill bookkeeping (loader waves): 16-byte stores with per-dword range check
+  const unsigned out_bytes = (unsigned)(item_elems * 4u);
+  __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(path + item_off, 0, out_bytes, 0x00020000);
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  // split the zero-fill evenly over the pipeline iterations (+ remainder after the loop)
+  const unsigned fill_step = (unsigned)kLoaders * 16u;
+  const unsigned n_fill = (out_bytes + fill_step - 1) / fill_step;      // strided passes in total
+  const unsigned fill_per_blk = n_blk > 0 ? (n_fill + n_blk - 1) / n_blk : n_fill;
+  unsigned fill_done = 0;
+
+  auto stage = [&](int k) {     // loaders: rows [k*R, k*R+R) -> ring slot k % kSlots
+    float* dst = ring + (size_t)(k % kSlots) * R * rs;
+    const int y0 = k * R;
+    for (int x = tid - 64; x < T_s; x += kLoaders) {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (y0 + r < t_y) dst[r * rs + x] = src[(size_t)(y0 + r) * T_s + x];
+    }
+  };
+  auto fill = [&](unsigned passes) {
+    for (unsigned p = 0; p < passes && fill_done < n_fill; ++p, ++fill_done) {
+      unsigned off = fill_done * fill_step + (unsigned)(tid - 64) * 16u;
+      if (off < out_bytes) __builtin_amdgcn_raw_buffer_store_b128(zero4, orsrc, off, 0, 0);
+    }
+  };
+
+  if (wave == 0) {
+    if (lane == 0 && status != nullptr) status[b] = valid ? 0 : 1;
+  } else {
+    if (n_blk > 0) stage(0);
+    if (n_blk > 1) stage(1);
+  }
+
+  // DP state of wave 0 (kept in registers across blocks)
+  const int x0 = lane * E;
+  float prev[E];
+  uint32_t acc[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) { prev[e] = kNeg; acc[e] = 0u; }
+  // Cell (0,0) is neg_cent[0][0] + max(v_prev = 0, v_cur = -1e9) (core.pyx:17-24).  Feeding it
+  // v_cur = 0 / v_prev = -1e9 gives the same sum and lets the shifted-in boundary value be the
+  // constant -1e9 on every row (the back-pointer bit of column 0 is never read: `index != 0`).
+  if (lane == 0) prev[0] = 0.0f;
+
+  __syncthreads();
+#pragma unroll 1
+  for (int k = 0; k < n_blk; ++k) {
+    if (wave == 0) {
+      const float* rows = ring + (size_t)(k % kSlots) * R * rs + x0;
+      const unsigned sh0 = (unsigned)(k & 1) * R;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int y = k * R + r;
+        float in[E];
+        read_chunk<E>(in, rows + r * rs);
+        const float left = wave_shr1(prev[E - 1], kNeg);         // value[y-1][x0-1]
+        float cur[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const float v_cur = prev[e];
+          const float v_prev = (e == 0) ? left : prev[e - 1];
+          const float m = (v_cur > v_prev) ? v_cur : v_prev;      // core.pyx:25 max(v_prev, v_cur)
+          const uint32_t bit = (v_cur < v_prev) ? 1u : 0u;        // core.pyx:32 backtrack test
+          cur[e] = in[e] + m;
+          acc[e] |= bit << (sh0 + r);
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) prev[e] = cur[e];
+        // cell (y, x = y+1) is what row y+1 reads as v_cur on its diagonal: the reference
+        // substitutes max_neg_val there (core.pyx:17-18).  (r+1)%E is a compile-time index.
+        prev[(r + 1) % E] = ((unsigned)lane == (unsigned)(y + 1) / E) ? kNeg : prev[(r + 1) % E];
+      }
+      if ((k & 1) || k == n_blk - 1) {
+        uint32_t* drow = dir + (size_t)(k >> 1) * TSP + x0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) { drow[e] = acc[e]; acc[e] = 0u; }
+      }
+    } else {
+      if (k + 2 < n_blk) stage(k + 2);
+      fill(fill_per_blk);
+    }
+    __syncthreads();
+  }
+  if (wave != 0) fill(n_fill);          // remainder (everything, for an invalid item)
+
+  // ---------------- backtrack (core.pyx:29-33) ----------------
+  if (valid && tid == 0) {
+    int index = t_x - 1;
+    for (int y = t_y - 1; y >= 0; --y) {
+      idxs[y] = index;
+      if (index != 0) {
+        const uint32_t w = dir[(size_t)(y >> 5) * TSP + index];
+        if (index == y || ((w >> (y & 31)) & 1u)) index--;
+      }
+    }
+  }
+  __syncthreads();
+  if (valid) {
+    uint32_t* out = path + item_off;
+    for (int y = tid; y < t_y; y += kThreads) out[(size_t)y * T_s + idxs[y]] = one_bits;
+  }
+}
+
+template <int E>
+int launch(const float* neg_cent, void* path, uint32_t one_bits, const int32_t* t_ys, const int32_t* t_xs,
+           int b, int t_t, int t_s, int32_t* status, hipStream_t stream) {
+  const size_t words = (size_t)((t_t + 31) >> 5) * (vits::kWave * E) + (size_t)((t_t + 3) & ~3) +
+                       (size_t)kSlots * R * ring_stride(t_s, E) + E;
+  const size_t lds = words * 4;
+  if (lds > (size_t)vits::kLdsBytesMax) return VITS_E_UNSUPPORTED;
+  auto kern = mas_kernel<E>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return vits::note_hip_error(e, "vits_mas_f32/attr");
+  }
+  hipLaunchKernelGGL(kern, dim3(b), dim3(kThreads), lds, stream, neg_cent, static_cast<uint32_t*>(path),
+                     t_ys, t_xs, t_t, t_s, one_bits, status);
+  return vits::check_launch("vits_mas_f32");
+}
+
+}  // namespace
+
+extern "C" int vits_mas_f32(const float* neg_cent, void* path, int path_dtype, const int32_t* t_ys,
+                            const int32_t* t_xs, int b, int t_t, int t_s, int32_t* status, void* stream) {
+  if (!neg_cent || !path || !t_ys || !t_xs || b <= 0 || t_t <= 0 || t_s <= 0) return VITS_E_BADARG;
+  uint32_t one_bits;
+  if (path_dtype == VITS_DT_F32) one_bits = 0x3F800000u;
+  else if (path_dtype == VITS_DT_I32) one_bits = 1u;
+  else return VITS_E_UNSUPPORTED;
+  if ((size_t)t_t * (size_t)t_s * 4 > 0xFFFFFFFFull) return VITS_E_UNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (t_s <= 64) return launch<1>(neg_cent, path, one_bits, t_ys, t_xs, b, t_t, t_s, status, s);
+  if (t_s <= 128) return launch<2>(neg_cent, path, one_bits, t_ys, t_xs, b, t_t, t_s, status, s);
+  if (t_s <= 256) return launch<4>(neg_cent, path, one_bits, t_ys, t_xs, b, t_t, t_s, status, s);
+  if (t_s <= 512) return launch<8>(neg_cent, path, one_bits, t_ys, t_xs, b, t_t, t_s, status, s);
+  if (t_s <= 1024) return launch<16>(neg_cent, path, one_bits, t_ys, t_xs, b, t_t, t_s, status, s);
+  return VITS_E_UNSUPPORTED;
+}
