@@ -57,8 +57,8 @@ const char* vits_last_error(void);
  *            1 <= t_x <= t_y <= t_t, t_x <= t_s.  Such an item gets an all-zero path (the
  *            reference reads out of bounds there: core.pyx:32 with wraparound(False)).
  *
- * Limits: t_s <= 1024; ceil(t_t/32) * roundup(t_s, 64*E) * 4 + 4*t_t bytes of LDS <= 160 KiB
- *         (t_t = 1000, t_s = 512 uses 68 KiB).  Otherwise VITS_E_UNSUPPORTED.
+ * Limits: t_s <= 1024; LDS = 4*(ceil(t_t/32)*w + t_t + 2*16*w) bytes <= 160 KiB, w = roundup(t_s, 16)
+ *         (t_t = 1000 fits up to t_s ~ 640; the reference caps t_s at 381).  Else VITS_E_UNSUPPORTED.
  * Result is bit-identical to the reference for NaN-free inputs (one fp32 add per cell).
  * ------------------------------------------------------------------------------------------ */
 int vits_mas_f32(const float* neg_cent, void* path, int path_dtype,

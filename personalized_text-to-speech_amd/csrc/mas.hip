@@ -28,7 +28,6 @@ constexpr float kNeg = -1e9f;            // max_neg_val of core.pyx:7 (exactly r
 constexpr int kThreads = 512;
 constexpr int kLoaders = kThreads - 64;
 constexpr int R = 16;                    // rows per pipeline block
-constexpr int kSlots = 3;                // LDS ring depth (blocks)
 
 __device__ __forceinline__ float wave_shr1(float src, float fill) {
   // lane l <- lane l-1; lane 0 <- fill   (DPP wave_shr:1, bound_ctrl off => keeps `old`)
@@ -65,10 +64,9 @@ __global__ __launch_bounds__(kThreads) void mas_kernel(const float* __restrict__
                                                        uint32_t* __restrict__ path,
                                                        const int* __restrict__ t_ys,
                                                        const int* __restrict__ t_xs,
-                                                       int T_t, int T_s,
+                                                       int T_t, int T_s, int n_slots,
                                                        uint32_t one_bits, int* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  constexpr int TSP = vits::kWave * E;           // padded row length of the bit matrix
 
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
@@ -82,9 +80,9 @@ __global__ __launch_bounds__(kThreads) void mas_kernel(const float* __restrict__
 
   const int nblk32 = (T_t + 31) >> 5;
   const int rs = ring_stride(T_s, E);
-  uint32_t* dir = smem;                                          // [nblk32][TSP] back-pointer bits
-  int* idxs = reinterpret_cast<int*>(dir + (size_t)nblk32 * TSP); // [T_t] path column per row
-  float* ring = reinterpret_cast<float*>(idxs + ((T_t + 3) & ~3)); // [kSlots][R][rs] (+E slack)
+  uint32_t* dir = smem;                                          // [nblk32][rs] back-pointer bits
+  int* idxs = reinterpret_cast<int*>(dir + (size_t)nblk32 * rs);  // [T_t] path column per row
+  float* ring = reinterpret_cast<float*>(idxs + ((T_t + 3) & ~3)); // [n_slots][R][rs]
 
   const int n_blk = valid ? (t_y + R - 1) / R : 0;               // pipeline blocks of R rows
   const float* src = neg_cent + item_off;
@@ -101,7 +99,7 @@ __global__ __launch_bounds__(kThreads) void mas_kernel(const float* __restrict__
   unsigned fill_done = 0;
 
   auto stage = [&](int k) {     // loaders: rows [k*R, k*R+R) -> ring slot k % kSlots
-    float* dst = ring + (size_t)(k % kSlots) * R * rs;
+    float* dst = ring + (size_t)(k % n_slots) * R * rs;
     const int y0 = k * R;
     for (int x = tid - 64; x < T_s; x += kLoaders) {
 #pragma unroll
@@ -119,12 +117,12 @@ __global__ __launch_bounds__(kThreads) void mas_kernel(const float* __restrict__
   if (wave == 0) {
     if (lane == 0 && status != nullptr) status[b] = valid ? 0 : 1;
   } else {
-    if (n_blk > 0) stage(0);
-    if (n_blk > 1) stage(1);
+    for (int k = 0; k < n_slots - 1 && k < n_blk; ++k) stage(k);
   }
 
   // DP state of wave 0 (kept in registers across blocks)
   const int x0 = lane * E;
+  const int xr = x0 < rs ? x0 : rs - E;          // lanes past the staged width re-read the last chunk (unused)
   float prev[E];
   uint32_t acc[E];
 #pragma unroll
@@ -138,7 +136,7 @@ __global__ __launch_bounds__(kThreads) void mas_kernel(const float* __restrict__
 #pragma unroll 1
   for (int k = 0; k < n_blk; ++k) {
     if (wave == 0) {
-      const float* rows = ring + (size_t)(k % kSlots) * R * rs + x0;
+      const float* rows = ring + (size_t)(k % n_slots) * R * rs + xr;
       const unsigned sh0 = (unsigned)(k & 1) * R;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -163,12 +161,16 @@ __global__ __launch_bounds__(kThreads) void mas_kernel(const float* __restrict__
         prev[(r + 1) % E] = ((unsigned)lane == (unsigned)(y + 1) / E) ? kNeg : prev[(r + 1) % E];
       }
       if ((k & 1) || k == n_blk - 1) {
-        uint32_t* drow = dir + (size_t)(k >> 1) * TSP + x0;
+        uint32_t* drow = dir + (size_t)(k >> 1) * rs + x0;
+        if (x0 < rs) {
 #pragma unroll
-        for (int e = 0; e < E; ++e) { drow[e] = acc[e]; acc[e] = 0u; }
+          for (int e = 0; e < E; ++e) drow[e] = acc[e];
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] = 0u;
       }
     } else {
-      if (k + 2 < n_blk) stage(k + 2);
+      if (k + n_slots - 1 < n_blk) stage(k + n_slots - 1);
       fill(fill_per_blk);
     }
     __syncthreads();
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(kThreads) void mas_kernel(const float* __restrict__
     for (int y = t_y - 1; y >= 0; --y) {
       idxs[y] = index;
       if (index != 0) {
-        const uint32_t w = dir[(size_t)(y >> 5) * TSP + index];
+        const uint32_t w = dir[(size_t)(y >> 5) * rs + index];
         if (index == y || ((w >> (y & 31)) & 1u)) index--;
       }
     }
@@ -196,9 +198,11 @@ __global__ __launch_bounds__(kThreads) void mas_kernel(const float* __restrict__
 template <int E>
 int launch(const float* neg_cent, void* path, uint32_t one_bits, const int32_t* t_ys, const int32_t* t_xs,
            int b, int t_t, int t_s, int32_t* status, hipStream_t stream) {
-  const size_t words = (size_t)((t_t + 31) >> 5) * (vits::kWave * E) + (size_t)((t_t + 3) & ~3) +
-                       (size_t)kSlots * R * ring_stride(t_s, E) + E;
-  const size_t lds = words * 4;
+  const size_t rs = ring_stride(t_s, E);
+  const size_t fixed = (size_t)((t_t + 31) >> 5) * rs + (size_t)((t_t + 3) & ~3);
+  int n_slots = 3;                                   // LDS ring depth: 3 blocks, 2 when LDS is short
+  if ((fixed + 3 * R * rs) * 4 > (size_t)vits::kLdsBytesMax) n_slots = 2;
+  const size_t lds = (fixed + (size_t)n_slots * R * rs) * 4;
   if (lds > (size_t)vits::kLdsBytesMax) return VITS_E_UNSUPPORTED;
   auto kern = mas_kernel<E>;
   if (lds > 64 * 1024) {
@@ -207,7 +211,7 @@ int launch(const float* neg_cent, void* path, uint32_t one_bits, const int32_t* 
     if (e != hipSuccess) return vits::note_hip_error(e, "vits_mas_f32/attr");
   }
   hipLaunchKernelGGL(kern, dim3(b), dim3(kThreads), lds, stream, neg_cent, static_cast<uint32_t*>(path),
-                     t_ys, t_xs, t_t, t_s, one_bits, status);
+                     t_ys, t_xs, t_t, t_s, n_slots, one_bits, status);
   return vits::check_launch("vits_mas_f32");
 }
 
