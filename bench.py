@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 22.05 kHz waveform samples / second of the VITS fine-tune step
+(G forward, D step, G step, two AdamW updates — reference finetune_speaker_v2.py:174-232) on
+N MI355X GPUs of one node, one process per GPU over RCCL.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): configs/modified_finetune_speaker.json
+(n_speakers=13), per-rank batch 16, T_y = linspace(200, 500) frames, T_x = 2*round(T_y/5)+1,
+bf16 autocast, synthetic seeded data, random-init weights.  Weak scaling: every rank runs the
+same per-rank batch on its own data.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def cpu_baseline(hps, cfgs, seconds_budget=25.0):
+    """The CPU path timed on this box's host cores (rank 0, N=1 only): the oracle's torch-cpu fp32
+    restatement of the same step + the C alignment DP (kind "port"), on a bounded sample:
+    batch 2, T_y = (120, 96) frames, as many steps as fit the budget (>= 1)."""
+    from importlib import import_module
+    from oracle import vits_torch as O
+    tr = import_module("personalized_text-to-speech_amd.train")
+    P = import_module("personalized_text-to-speech_amd")
+    torch.manual_seed(0)
+    m = {k: v for k, v in hps.model.items()}
+    g = P.SynthesizerTrn(hps.n_symbols, hps.data.filter_length // 2 + 1, hps.train.segment_size // hps.data.hop_length,
+                         n_speakers=hps.data.n_speakers, **m)
+    d = P.MultiPeriodDiscriminator(False)
+    sd_g = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in g.state_dict().items()}
+    sd_d = {k: v.detach().clone().requires_grad_(True) for k, v in d.state_dict().items()}
+    del g, d
+    opt_g = torch.optim.AdamW([v for v in sd_g.values() if v.requires_grad], hps.train.learning_rate, betas=hps.train.betas, eps=hps.train.eps)
+    opt_d = torch.optim.AdamW(list(sd_d.values()), hps.train.learning_rate, betas=hps.train.betas, eps=hps.train.eps)
+    B = 2
+    # the product's synthetic-batch maker needs the HIP-free spectrogram: build the batch with the oracle's
+    x, x_len, _, t_y, wav, wav_len, sid = tr.synthetic_batch.__wrapped__(hps, B, (96, 120), "cpu") if hasattr(tr.synthetic_batch, "__wrapped__") else tr.synthetic_batch(hps, B, (96, 120), "cpu")
+    spec = O.spectrogram(wav.squeeze(1), hps.data.filter_length, hps.data.hop_length, hps.data.win_length)
+    spec = spec * (torch.arange(spec.size(2))[None, :] < t_y[:, None])[:, None, :]
+    batch = (x, x_len, spec, t_y, wav, wav_len, sid)
+    hp = dict(hps.data); hp.update(hps.train)
+    H, T_x = hps.model.hidden_channels, x.size(1)
+    steps, t_total = 0, 0.0
+    while True:
+        noise = [torch.randn(B, hps.model.inter_channels, spec.size(2)), torch.randn(B, 2, T_x), torch.rand(B)]
+        t0 = time.perf_counter()
+        loss_disc, rest = O.train_losses(sd_g, sd_d, hps.model, hp, batch, noise)
+        opt_d.zero_grad(); loss_disc.backward(); opt_d.step()
+        loss_gen_all, _ = O.generator_losses(sd_d, hp, *rest)
+        opt_g.zero_grad(); loss_gen_all.backward(); opt_g.step()
+        t_total += time.perf_counter() - t0
+        steps += 1
+        if t_total > seconds_budget or steps >= 8:
+            break
+    return dict(value=B * hps.train.segment_size * steps / t_total, unit="samples/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"oracle torch-cpu fp32 step + C alignment DP, batch {B}, T_y=(120,96), {steps} step(s), {t_total:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="C2")
+    ap.add_argument("--fp32", action="store_true", help="parity mode: no bf16 autocast")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from importlib import import_module
+    P = import_module("personalized_text-to-speech_amd")
+    cfgs = import_module("personalized_text-to-speech_amd.configs")
+    tr = import_module("personalized_text-to-speech_amd.train")
+    P._lib.lib()                                          # fail loudly if the HIP library is missing
+
+    cfg_name, batch_size, t_y_range = cfgs.WORKLOADS[args.workload]
+    hps = cfgs.get(cfg_name)
+    tuner = tr.FineTuner(hps, device, amp=not args.fp32)
+    batch = tr.synthetic_batch(hps, batch_size, t_y_range, device, rank=rank)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = tuner.step(batch)
+    P._lib.timer.enabled = True
+    P._lib.timer.reset()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = tuner.step(batch)
+    sync()
+    elapsed = time.perf_counter() - t0
+    P._lib.timer.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    losses = {k: float(v) for k, v in out.items()}
+    if not all(v == v and abs(v) != float("inf") for v in losses.values()):
+        raise SystemExit(f"non-finite losses: {losses}")
+
+    if rank == 0:
+        samples = world * batch_size * hps.train.segment_size * args.steps
+        T_x, T_y = batch[0].size(1), batch[2].size(2)
+        # roofline of the dominant hand-written kernel: algorithmic bytes
+        # per launch / average launch time from HIP events recorded inside the timed region
+        summ = P._lib.timer.summary()
+        roof = None
+        if "vits_mas_f32" in summ:
+            s = summ["vits_mas_f32"]
+            bytes_per_launch = 8.0 * s["units_per_call"]            # 4 B read + 4 B written per DP cell
+            achieved = bytes_per_launch / (s["avg_ms"] * 1e-3) / 1e9
+            roof = dict(kernel="mas_kernel (vits_mas_f32)", bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=achieved / HBM_PEAK_GBS, traffic=None, avg_launch_us=s["avg_ms"] * 1e3,
+                        bytes_per_launch=bytes_per_launch, launches=s["calls"])
+        line = dict(metric="22.05 kHz waveform samples/sec, VITS fine-tune fwd+bwd", value=samples / elapsed, unit="samples/s",
+                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3,
+                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="fp32" if args.fp32 else "bf16",
+                    data="synthetic",
+                    config=dict(workload=f"{args.workload}: {cfg_name}.json, per-rank batch {batch_size}, T_y<= {T_y} frames, "
+                                         f"T_x<= {T_x} tokens, segment {hps.train.segment_size} samples, fwd+bwd+AdamW (G and D)",
+                                parallelism=f"dp{world}", kernels=P.kernels.BACKENDS, losses=losses),
+                    roofline=roof)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(hps, cfgs)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

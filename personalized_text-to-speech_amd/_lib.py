@@ -73,6 +73,45 @@ def check(rc, what):
         raise VitsKernelError(f"{what}: {_CODES.get(rc, rc)} {detail}")
 
 
+class KernelTimer:
+    """Optional HIP-event timing of the C-ABI launches, per kernel name (bench.py's roofline leg).
+    Events are recorded on the stream the kernel is launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.enabled = False
+        self.events = {}          # name -> [(start, end, units)]
+
+    def start(self, name):
+        if not self.enabled:
+            return None
+        import torch
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return e0
+
+    def stop(self, name, e0, units):
+        if e0 is None:
+            return
+        import torch
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.events.setdefault(name, []).append((e0, e1, units))
+
+    def summary(self):
+        """name -> dict(calls, avg_ms, units_per_call); call after torch.cuda.synchronize()."""
+        out = {}
+        for name, ev in self.events.items():
+            ms = [a.elapsed_time(b) for a, b, _ in ev]
+            out[name] = dict(calls=len(ev), avg_ms=sum(ms) / len(ms), units_per_call=sum(u for _, _, u in ev) / len(ev))
+        return out
+
+    def reset(self):
+        self.events = {}
+
+
+timer = KernelTimer()
+
+
 def stream_ptr():
     """The hipStream_t of torch's current stream, as an integer for the C ABI."""
     import torch

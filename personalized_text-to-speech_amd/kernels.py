@@ -1,0 +1,124 @@
+"""Operator layer of the hot path: every function here is what the nn.Modules call.
+
+Each op is either
+  * HIP  — a hand-written gfx950 kernel reached through the C ABI of libvitsmi.so (include/vitsmi.h),
+           wrapped in a torch.autograd.Function where it needs a backward; or
+  * ROCm — a composition of PyTorch-ROCm device ops (MIOpen / rocBLAS), for ops whose HIP kernel has
+           not landed yet.  DESIGN.md §kernels lists which is which; `BACKENDS` below is the same
+           table in code, and bench.py prints it.
+There is no CPU implementation of the HIP ops: they raise on non-GPU tensors.
+"""
+import math
+
+import torch
+from torch.nn import functional as F
+
+from . import _lib
+from . import monotonic_align as _ma
+
+BACKENDS = {
+    "maximum_path": "hip",
+    "conv1d": "rocm",
+    "conv_transpose1d": "rocm",
+    "weight_norm": "rocm",
+    "wn_gate": "rocm",
+    "layer_norm_c": "rocm",
+    "rel_attention": "rocm",
+    "rq_spline": "rocm",
+    "stft_magnitude": "rocm",
+}
+
+
+# ------------------------------------------------------------------ alignment (HIP)
+def maximum_path(neg_cent, mask):
+    return _ma.maximum_path(neg_cent, mask)
+
+
+# ------------------------------------------------------------------ convolutions
+def weight_norm(v, g):
+    """w = g * v / ||v||_2, norm over every dim but 0 (legacy torch.nn.utils.weight_norm, dim=0;
+    reference models.py:254, modules.py:128,135,145,191-206).  For ConvTranspose1d weights
+    [c_in, c_out, k] dim 0 is the INPUT channel."""
+    norm = torch.linalg.vector_norm(v.float(), 2, dim=tuple(range(1, v.dim())), keepdim=True)
+    return (v.float() * (g.float() / norm)).to(v.dtype)
+
+
+def conv1d(x, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
+    return F.conv1d(x, weight.to(x.dtype), None if bias is None else bias.to(x.dtype), stride, padding, dilation, groups)
+
+
+def conv_transpose1d(x, weight, bias=None, stride=1, padding=0):
+    return F.conv_transpose1d(x, weight.to(x.dtype), None if bias is None else bias.to(x.dtype), stride, padding)
+
+
+def leaky_relu(x, slope):
+    return F.leaky_relu(x, slope)
+
+
+def wn_gate(x_in, g_l, n_channels):
+    """tanh((a+b)[:, :C]) * sigmoid((a+b)[:, C:]) (reference commons.py:103-110)."""
+    if g_l is not None:
+        x_in = x_in + g_l
+    return torch.tanh(x_in[:, :n_channels]) * torch.sigmoid(x_in[:, n_channels:])
+
+
+# ------------------------------------------------------------------ normalisation
+def layer_norm_c(x, gamma, beta, eps):
+    """LayerNorm over the CHANNEL dim of [b, c, t] (reference modules.py:20-32)."""
+    xt = x.transpose(1, -1)
+    xt = F.layer_norm(xt.float(), (x.size(1),), gamma.float(), beta.float(), eps).to(x.dtype)
+    return xt.transpose(1, -1)
+
+
+# ------------------------------------------------------------------ relative-position attention
+def rel_attention(q, k, v, emb_rel_k, emb_rel_v, mask, n_heads, window_size, p_dropout=0.0, training=False):
+    """Windowed relative-position self-attention (reference attentions.py:150-182).
+
+    q, k, v: [b, d, t];  emb_rel_*: [1, 2w+1, d/h] (shared by the heads);  mask: [b, 1, t, t] or None.
+    scores[i,j] = q_i.k_j/sqrt(dk) + (|j-i| <= w) q_i.E_k[j-i+w]/sqrt(dk);  masked_fill(mask==0, -1e4);
+    out_i = sum_j p_ij v_j + sum_{|r|<=w} p_{i,i+r} E_v[r+w].
+    The reference materialises the band with pad/reshape skews (attentions.py:199-243); here the
+    band is gathered/scattered directly through a [t, t] relative-index map.
+    Returns (out [b, d, t], p_attn [b, h, t, t]).
+    """
+    b, d, t = q.shape
+    dk = d // n_heads
+    qh = q.view(b, n_heads, dk, t).transpose(2, 3) / math.sqrt(dk)       # [b,h,t,dk]
+    kh = k.view(b, n_heads, dk, t).transpose(2, 3)
+    vh = v.view(b, n_heads, dk, t).transpose(2, 3)
+    scores = torch.matmul(qh, kh.transpose(-2, -1))                       # [b,h,t,t]
+    pos = torch.arange(t, device=q.device)
+    rel = pos[None, :] - pos[:, None] + window_size                       # [t,t] index into 2w+1
+    band = (rel >= 0) & (rel <= 2 * window_size)
+    relc = rel.clamp(0, 2 * window_size)
+    rel_logits = torch.matmul(qh, emb_rel_k.to(q.dtype).unsqueeze(0).transpose(-2, -1))   # [b,h,t,2w+1]
+    scores = scores + torch.where(band, rel_logits.gather(-1, relc.expand(b, n_heads, t, t)), torch.zeros((), dtype=q.dtype, device=q.device))
+    if mask is not None:
+        scores = scores.masked_fill(mask == 0, -1e4)
+    p_attn = F.softmax(scores, dim=-1)
+    p_drop = F.dropout(p_attn, p_dropout, training) if p_dropout > 0 else p_attn
+    out = torch.matmul(p_drop, vh)
+    # relative values: weights[b,h,i,r] = p[i, i+r-w]
+    w_rel = torch.zeros(b, n_heads, t, 2 * window_size + 1, dtype=q.dtype, device=q.device)
+    w_rel = w_rel.scatter_add(-1, relc.expand(b, n_heads, t, t), p_drop * band.to(q.dtype))
+    out = out + torch.matmul(w_rel, emb_rel_v.to(q.dtype).unsqueeze(0))
+    out = out.transpose(2, 3).contiguous().view(b, d, t)
+    return out, p_attn
+
+
+# ------------------------------------------------------------------ spline
+def rq_spline(inputs, uw, uh, ud, inverse, tail_bound, min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3):
+    from .transforms import rq_spline_torch
+    return rq_spline_torch(inputs.float(), uw.float(), uh.float(), ud.float(), inverse, tail_bound,
+                           min_bin_width, min_bin_height, min_derivative)
+
+
+# ------------------------------------------------------------------ STFT
+def stft_magnitude(y, n_fft, hop, win, window):
+    """reflect-pad (n_fft-hop)/2, framed real DFT with `window`, sqrt(re^2+im^2+1e-6)
+    (reference mel_processing.py:63-69).  y [b, t] -> [b, n_fft/2+1, frames]."""
+    pad = int((n_fft - hop) / 2)
+    yp = F.pad(y.unsqueeze(1), (pad, pad), mode="reflect").squeeze(1)
+    spec = torch.stft(yp, n_fft, hop_length=hop, win_length=win, window=window, center=False,
+                      normalized=False, onesided=True, return_complex=True)
+    return torch.sqrt(spec.real.pow(2) + spec.imag.pow(2) + 1e-6)

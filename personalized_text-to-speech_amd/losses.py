@@ -1,0 +1,42 @@
+"""Mirror of the reference's losses.py:7-61 (same names, arguments, results).  The only change:
+discriminator_loss returns its per-discriminator terms as tensors, not `.item()` floats (12 host
+syncs per step in the reference, losses.py:28-29)."""
+import torch
+
+
+def feature_loss(fmap_r, fmap_g):
+    loss = 0
+    for dr, dg in zip(fmap_r, fmap_g):
+        for rl, gl in zip(dr, dg):
+            loss = loss + torch.mean(torch.abs(rl.float().detach() - gl.float()))
+    return loss * 2
+
+
+def discriminator_loss(disc_real_outputs, disc_generated_outputs):
+    loss = 0
+    r_losses, g_losses = [], []
+    for dr, dg in zip(disc_real_outputs, disc_generated_outputs):
+        r_loss = torch.mean((1 - dr.float()) ** 2)
+        g_loss = torch.mean(dg.float() ** 2)
+        loss = loss + (r_loss + g_loss)
+        r_losses.append(r_loss.detach())
+        g_losses.append(g_loss.detach())
+    return loss, r_losses, g_losses
+
+
+def generator_loss(disc_outputs):
+    loss = 0
+    gen_losses = []
+    for dg in disc_outputs:
+        l = torch.mean((1 - dg.float()) ** 2)
+        gen_losses.append(l)
+        loss = loss + l
+    return loss, gen_losses
+
+
+def kl_loss(z_p, logs_q, m_p, logs_p, z_mask):
+    """z_p, logs_q, m_p, logs_p: [b, h, t_t] (argument order of reference losses.py:46)."""
+    z_p, logs_q, m_p, logs_p, z_mask = (t.float() for t in (z_p, logs_q, m_p, logs_p, z_mask))
+    kl = logs_p - logs_q - 0.5
+    kl = kl + 0.5 * ((z_p - m_p) ** 2) * torch.exp(-2.0 * logs_p)
+    return torch.sum(kl * z_mask) / torch.sum(z_mask)

@@ -1,0 +1,414 @@
+"""VITS generator and discriminators — mirror of the reference's models.py: same class names,
+constructor signatures, parameter names (state_dict keys, incl. weight_g / weight_v) and return
+tuples, so checkpoints and callers are interchangeable.  File:line citations point at the reference.
+"""
+import math
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from . import attentions
+from . import commons
+from . import kernels as K
+from . import modules
+from .commons import get_padding
+from .modules import Conv1d, WNConv1d, WNConvTranspose1d
+from .rng import noise
+
+
+class StochasticDurationPredictor(nn.Module):
+    # models.py:17-95
+    def __init__(self, in_channels, filter_channels, kernel_size, p_dropout, n_flows=4, gin_channels=0):
+        super().__init__()
+        filter_channels = in_channels        # models.py:20 ("it needs to be removed from future version")
+        self.in_channels, self.filter_channels, self.kernel_size = in_channels, filter_channels, kernel_size
+        self.p_dropout, self.n_flows, self.gin_channels = p_dropout, n_flows, gin_channels
+
+        self.log_flow = modules.Log()
+        self.flows = nn.ModuleList()
+        self.flows.append(modules.ElementwiseAffine(2))
+        for _ in range(n_flows):
+            self.flows.append(modules.ConvFlow(2, filter_channels, kernel_size, n_layers=3))
+            self.flows.append(modules.Flip())
+
+        self.post_pre = Conv1d(1, filter_channels, 1)
+        self.post_proj = Conv1d(filter_channels, filter_channels, 1)
+        self.post_convs = modules.DDSConv(filter_channels, kernel_size, n_layers=3, p_dropout=p_dropout)
+        self.post_flows = nn.ModuleList()
+        self.post_flows.append(modules.ElementwiseAffine(2))
+        for _ in range(4):
+            self.post_flows.append(modules.ConvFlow(2, filter_channels, kernel_size, n_layers=3))
+            self.post_flows.append(modules.Flip())
+
+        self.pre = Conv1d(in_channels, filter_channels, 1)
+        self.proj = Conv1d(filter_channels, filter_channels, 1)
+        self.convs = modules.DDSConv(filter_channels, kernel_size, n_layers=3, p_dropout=p_dropout)
+        if gin_channels != 0:
+            self.cond = Conv1d(gin_channels, filter_channels, 1)
+
+    def forward(self, x, x_mask, w=None, g=None, reverse=False, noise_scale=1.0):
+        x = self.pre(torch.detach(x))
+        if g is not None:
+            x = x + self.cond(torch.detach(g))
+        x = self.convs(x, x_mask)
+        x = self.proj(x) * x_mask
+
+        if not reverse:
+            assert w is not None
+            logdet_tot_q = 0
+            h_w = self.post_pre(w)
+            h_w = self.post_convs(h_w, x_mask)
+            h_w = self.post_proj(h_w) * x_mask
+            e_q = noise.randn(w.size(0), 2, w.size(2), device=x.device, dtype=x.dtype) * x_mask
+            z_q = e_q
+            for flow in self.post_flows:
+                z_q, logdet_q = flow(z_q, x_mask, g=(x + h_w))
+                logdet_tot_q = logdet_tot_q + logdet_q
+            z_u, z1 = torch.split(z_q, [1, 1], 1)
+            u = torch.sigmoid(z_u) * x_mask
+            z0 = (w - u) * x_mask
+            logdet_tot_q = logdet_tot_q + torch.sum((F.logsigmoid(z_u) + F.logsigmoid(-z_u)) * x_mask, [1, 2])
+            logq = torch.sum(-0.5 * (commons.LOG_2PI + (e_q ** 2)) * x_mask, [1, 2]) - logdet_tot_q
+
+            logdet_tot = 0
+            z0, logdet = self.log_flow(z0, x_mask)
+            logdet_tot = logdet_tot + logdet
+            z = torch.cat([z0, z1], 1)
+            for flow in self.flows:
+                z, logdet = flow(z, x_mask, g=x, reverse=reverse)
+                logdet_tot = logdet_tot + logdet
+            nll = torch.sum(0.5 * (commons.LOG_2PI + (z ** 2)) * x_mask, [1, 2]) - logdet_tot
+            return nll + logq                                     # [b]
+        flows = list(reversed(self.flows))
+        flows = flows[:-2] + [flows[-1]]                          # models.py:88-89 "remove a useless vflow"
+        z = noise.randn(x.size(0), 2, x.size(2), device=x.device, dtype=x.dtype) * noise_scale
+        for flow in flows:
+            z = flow(z, x_mask, g=x, reverse=reverse)
+        z0, z1 = torch.split(z, [1, 1], 1)
+        return z0                                                 # logw
+
+
+class DurationPredictor(nn.Module):
+    # models.py:98-132 (used only with use_sdp=False)
+    def __init__(self, in_channels, filter_channels, kernel_size, p_dropout, gin_channels=0):
+        super().__init__()
+        self.in_channels, self.filter_channels, self.kernel_size = in_channels, filter_channels, kernel_size
+        self.p_dropout, self.gin_channels = p_dropout, gin_channels
+        self.drop = nn.Dropout(p_dropout)
+        self.conv_1 = Conv1d(in_channels, filter_channels, kernel_size, padding=kernel_size // 2)
+        self.norm_1 = modules.LayerNorm(filter_channels)
+        self.conv_2 = Conv1d(filter_channels, filter_channels, kernel_size, padding=kernel_size // 2)
+        self.norm_2 = modules.LayerNorm(filter_channels)
+        self.proj = Conv1d(filter_channels, 1, 1)
+        if gin_channels != 0:
+            self.cond = Conv1d(gin_channels, in_channels, 1)
+
+    def forward(self, x, x_mask, g=None):
+        x = torch.detach(x)
+        if g is not None:
+            x = x + self.cond(torch.detach(g))
+        x = self.drop(self.norm_1(torch.relu(self.conv_1(x * x_mask))))
+        x = self.drop(self.norm_2(torch.relu(self.conv_2(x * x_mask))))
+        return self.proj(x * x_mask) * x_mask
+
+
+class TextEncoder(nn.Module):
+    # models.py:135-176
+    def __init__(self, n_vocab, out_channels, hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout):
+        super().__init__()
+        self.n_vocab, self.out_channels, self.hidden_channels, self.filter_channels = n_vocab, out_channels, hidden_channels, filter_channels
+        self.n_heads, self.n_layers, self.kernel_size, self.p_dropout = n_heads, n_layers, kernel_size, p_dropout
+        self.emb = nn.Embedding(n_vocab, hidden_channels)
+        nn.init.normal_(self.emb.weight, 0.0, hidden_channels ** -0.5)
+        self.encoder = attentions.Encoder(hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout)
+        self.proj = Conv1d(hidden_channels, out_channels * 2, 1)
+
+    def forward(self, x, x_lengths):
+        x = self.emb(x) * math.sqrt(self.hidden_channels)         # [b, t, h]
+        x = torch.transpose(x, 1, -1)                             # [b, h, t]
+        x_mask = torch.unsqueeze(commons.sequence_mask(x_lengths, x.size(2)), 1).to(x.dtype)
+        x = self.encoder(x * x_mask, x_mask)
+        stats = self.proj(x) * x_mask
+        m, logs = torch.split(stats, self.out_channels, dim=1)
+        return x, m, logs, x_mask
+
+
+class ResidualCouplingBlock(nn.Module):
+    # models.py:179-209
+    def __init__(self, channels, hidden_channels, kernel_size, dilation_rate, n_layers, n_flows=4, gin_channels=0):
+        super().__init__()
+        self.channels, self.hidden_channels, self.kernel_size = channels, hidden_channels, kernel_size
+        self.dilation_rate, self.n_layers, self.n_flows, self.gin_channels = dilation_rate, n_layers, n_flows, gin_channels
+        self.flows = nn.ModuleList()
+        for _ in range(n_flows):
+            self.flows.append(modules.ResidualCouplingLayer(channels, hidden_channels, kernel_size, dilation_rate, n_layers,
+                                                            gin_channels=gin_channels, mean_only=True))
+            self.flows.append(modules.Flip())
+
+    def forward(self, x, x_mask, g=None, reverse=False):
+        if not reverse:
+            for flow in self.flows:
+                x, _ = flow(x, x_mask, g=g, reverse=reverse)
+        else:
+            for flow in reversed(self.flows):
+                x = flow(x, x_mask, g=g, reverse=reverse)
+        return x
+
+
+class PosteriorEncoder(nn.Module):
+    # models.py:212-241
+    def __init__(self, in_channels, out_channels, hidden_channels, kernel_size, dilation_rate, n_layers, gin_channels=0):
+        super().__init__()
+        self.in_channels, self.out_channels, self.hidden_channels = in_channels, out_channels, hidden_channels
+        self.kernel_size, self.dilation_rate, self.n_layers, self.gin_channels = kernel_size, dilation_rate, n_layers, gin_channels
+        self.pre = Conv1d(in_channels, hidden_channels, 1)
+        self.enc = modules.WN(hidden_channels, kernel_size, dilation_rate, n_layers, gin_channels=gin_channels)
+        self.proj = Conv1d(hidden_channels, out_channels * 2, 1)
+
+    def forward(self, x, x_lengths, g=None):
+        x_mask = torch.unsqueeze(commons.sequence_mask(x_lengths, x.size(2)), 1).to(x.dtype)
+        x = self.pre(x) * x_mask
+        x = self.enc(x, x_mask, g=g)
+        stats = self.proj(x) * x_mask
+        m, logs = torch.split(stats, self.out_channels, dim=1)
+        z = (m + noise.randn_like(m) * torch.exp(logs)) * x_mask
+        return z, m, logs, x_mask
+
+
+class Generator(nn.Module):
+    # models.py:244-296 (HiFi-GAN decoder)
+    def __init__(self, initial_channel, resblock, resblock_kernel_sizes, resblock_dilation_sizes, upsample_rates,
+                 upsample_initial_channel, upsample_kernel_sizes, gin_channels=0):
+        super().__init__()
+        self.num_kernels = len(resblock_kernel_sizes)
+        self.num_upsamples = len(upsample_rates)
+        self.conv_pre = Conv1d(initial_channel, upsample_initial_channel, 7, 1, padding=3)
+        resblock_cls = modules.ResBlock1 if resblock == "1" else modules.ResBlock2
+
+        self.ups = nn.ModuleList()
+        for i, (u, k) in enumerate(zip(upsample_rates, upsample_kernel_sizes)):
+            self.ups.append(WNConvTranspose1d(upsample_initial_channel // (2 ** i), upsample_initial_channel // (2 ** (i + 1)),
+                                              k, u, padding=(k - u) // 2))
+        self.resblocks = nn.ModuleList()
+        for i in range(len(self.ups)):
+            ch = upsample_initial_channel // (2 ** (i + 1))
+            for k, d in zip(resblock_kernel_sizes, resblock_dilation_sizes):
+                self.resblocks.append(resblock_cls(ch, k, d))
+        self.conv_post = Conv1d(ch, 1, 7, 1, padding=3, bias=False)
+        modules._burn_init_weights(self.ups)                       # models.py:265 `self.ups.apply(init_weights)`
+        if gin_channels != 0:
+            self.cond = Conv1d(gin_channels, upsample_initial_channel, 1)
+
+    def forward(self, x, g=None):
+        x = self.conv_pre(x)
+        if g is not None:
+            x = x + self.cond(g)
+        for i in range(self.num_upsamples):
+            x = K.leaky_relu(x, modules.LRELU_SLOPE)
+            x = self.ups[i](x)
+            xs = None
+            for j in range(self.num_kernels):
+                r = self.resblocks[i * self.num_kernels + j](x)
+                xs = r if xs is None else xs + r
+            x = xs / self.num_kernels
+        x = K.leaky_relu(x, 0.01)                                  # models.py:285: F.leaky_relu default slope
+        x = self.conv_post(x)
+        return torch.tanh(x)
+
+    def remove_weight_norm(self):
+        raise NotImplementedError("weight-norm folding for inference is SURVEY §8 (f-2), not built yet")
+
+
+class _WNConv2dK1(nn.Module):
+    """weight_norm(Conv2d(cin, cout, (k,1), (s,1), padding=(p,0))) of DiscriminatorP (models.py:304-312);
+    parameters `bias`, `weight_g` [cout,1,1,1], `weight_v` [cout,cin,k,1]."""
+
+    def __init__(self, cin, cout, k, s, p):
+        super().__init__()
+        proto = nn.Conv2d(cin, cout, (k, 1), (s, 1), padding=(p, 0))
+        self.stride, self.padding = (s, 1), (p, 0)
+        self.bias = nn.Parameter(proto.bias.data)
+        v = proto.weight.data
+        self.weight_g = nn.Parameter(torch.linalg.vector_norm(v, 2, dim=(1, 2, 3), keepdim=True))
+        self.weight_v = nn.Parameter(v)
+
+    def forward(self, x):
+        w = K.weight_norm(self.weight_v, self.weight_g)
+        return F.conv2d(x, w.to(x.dtype), self.bias.to(x.dtype), self.stride, self.padding)
+
+
+class DiscriminatorP(nn.Module):
+    # models.py:299-335
+    def __init__(self, period, kernel_size=5, stride=3, use_spectral_norm=False):
+        super().__init__()
+        if use_spectral_norm:
+            raise NotImplementedError("use_spectral_norm=False in every reference config")
+        self.period = period
+        self.use_spectral_norm = use_spectral_norm
+        p = get_padding(kernel_size, 1)
+        self.convs = nn.ModuleList([
+            _WNConv2dK1(1, 32, kernel_size, stride, p), _WNConv2dK1(32, 128, kernel_size, stride, p),
+            _WNConv2dK1(128, 512, kernel_size, stride, p), _WNConv2dK1(512, 1024, kernel_size, stride, p),
+            _WNConv2dK1(1024, 1024, kernel_size, 1, p)])
+        self.conv_post = _WNConv2dK1(1024, 1, 3, 1, 1)
+
+    def forward(self, x):
+        fmap = []
+        b, c, t = x.shape
+        if t % self.period != 0:                                   # pad first (models.py:319-322)
+            n_pad = self.period - (t % self.period)
+            x = F.pad(x, (0, n_pad), "reflect")
+            t = t + n_pad
+        x = x.view(b, c, t // self.period, self.period)
+        for l in self.convs:
+            x = F.leaky_relu(l(x), modules.LRELU_SLOPE)
+            fmap.append(x)
+        x = self.conv_post(x)
+        fmap.append(x)
+        return torch.flatten(x, 1, -1), fmap
+
+
+class DiscriminatorS(nn.Module):
+    # models.py:338-361
+    def __init__(self, use_spectral_norm=False):
+        super().__init__()
+        if use_spectral_norm:
+            raise NotImplementedError("use_spectral_norm=False in every reference config")
+        self.convs = nn.ModuleList([
+            WNConv1d(1, 16, 15, 1, padding=7), WNConv1d(16, 64, 41, 4, groups=4, padding=20),
+            WNConv1d(64, 256, 41, 4, groups=16, padding=20), WNConv1d(256, 1024, 41, 4, groups=64, padding=20),
+            WNConv1d(1024, 1024, 41, 4, groups=256, padding=20), WNConv1d(1024, 1024, 5, 1, padding=2)])
+        self.conv_post = WNConv1d(1024, 1, 3, 1, padding=1)
+
+    def forward(self, x):
+        fmap = []
+        for l in self.convs:
+            x = F.leaky_relu(l(x), modules.LRELU_SLOPE)
+            fmap.append(x)
+        x = self.conv_post(x)
+        fmap.append(x)
+        return torch.flatten(x, 1, -1), fmap
+
+
+class MultiPeriodDiscriminator(nn.Module):
+    # models.py:364-386
+    def __init__(self, use_spectral_norm=False):
+        super().__init__()
+        periods = [2, 3, 5, 7, 11]
+        discs = [DiscriminatorS(use_spectral_norm=use_spectral_norm)]
+        discs = discs + [DiscriminatorP(i, use_spectral_norm=use_spectral_norm) for i in periods]
+        self.discriminators = nn.ModuleList(discs)
+
+    def forward(self, y, y_hat):
+        """Real and generated waveforms go through each discriminator as ONE batch of 2b (the
+        reference runs them as two passes, models.py:375-377; the convolutions have no cross-batch
+        coupling, so the results are identical and every kernel sees twice the rows)."""
+        b = y.size(0)
+        yy = torch.cat([y, y_hat], 0)
+        y_d_rs, y_d_gs, fmap_rs, fmap_gs = [], [], [], []
+        for d in self.discriminators:
+            out, fmap = d(yy)
+            y_d_rs.append(out[:b]); y_d_gs.append(out[b:])
+            fmap_rs.append([f[:b] for f in fmap]); fmap_gs.append([f[b:] for f in fmap])
+        return y_d_rs, y_d_gs, fmap_rs, fmap_gs
+
+
+class SynthesizerTrn(nn.Module):
+    """Synthesizer for training (models.py:390-533)."""
+
+    def __init__(self, n_vocab, spec_channels, segment_size, inter_channels, hidden_channels, filter_channels, n_heads,
+                 n_layers, kernel_size, p_dropout, resblock, resblock_kernel_sizes, resblock_dilation_sizes, upsample_rates,
+                 upsample_initial_channel, upsample_kernel_sizes, n_speakers=0, gin_channels=0, use_sdp=True, **kwargs):
+        super().__init__()
+        self.n_vocab, self.spec_channels, self.inter_channels, self.hidden_channels = n_vocab, spec_channels, inter_channels, hidden_channels
+        self.filter_channels, self.n_heads, self.n_layers, self.kernel_size, self.p_dropout = filter_channels, n_heads, n_layers, kernel_size, p_dropout
+        self.resblock, self.resblock_kernel_sizes, self.resblock_dilation_sizes = resblock, resblock_kernel_sizes, resblock_dilation_sizes
+        self.upsample_rates, self.upsample_initial_channel, self.upsample_kernel_sizes = upsample_rates, upsample_initial_channel, upsample_kernel_sizes
+        self.segment_size, self.n_speakers, self.gin_channels, self.use_sdp = segment_size, n_speakers, gin_channels, use_sdp
+
+        self.enc_p = TextEncoder(n_vocab, inter_channels, hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout)
+        self.dec = Generator(inter_channels, resblock, resblock_kernel_sizes, resblock_dilation_sizes, upsample_rates,
+                             upsample_initial_channel, upsample_kernel_sizes, gin_channels=gin_channels)
+        self.enc_q = PosteriorEncoder(spec_channels, inter_channels, hidden_channels, 5, 1, 16, gin_channels=gin_channels)
+        self.flow = ResidualCouplingBlock(inter_channels, hidden_channels, 5, 1, 4, gin_channels=gin_channels)
+        if use_sdp:
+            self.dp = StochasticDurationPredictor(hidden_channels, 192, 3, 0.5, 4, gin_channels=gin_channels)
+        else:
+            self.dp = DurationPredictor(hidden_channels, 256, 3, 0.5, gin_channels=gin_channels)
+        if n_speakers >= 1:
+            self.emb_g = nn.Embedding(n_speakers, gin_channels)
+
+    def _speaker(self, sid):
+        return self.emb_g(sid).unsqueeze(-1) if self.n_speakers > 0 else None     # [b, h, 1]
+
+    @staticmethod
+    def neg_cent(z_p, m_p, logs_p):
+        """Negative cross-entropy of every (frame, token) pair (models.py:470-477), fp32."""
+        z_p, m_p, logs_p = z_p.float(), m_p.float(), logs_p.float()
+        s_p_sq_r = torch.exp(-2 * logs_p)                                              # [b, d, t_s]
+        neg_cent1 = torch.sum(-0.5 * commons.LOG_2PI - logs_p, [1], keepdim=True)      # [b, 1, t_s]
+        neg_cent2 = torch.matmul(-0.5 * (z_p ** 2).transpose(1, 2), s_p_sq_r)          # [b, t_t, t_s]
+        neg_cent3 = torch.matmul(z_p.transpose(1, 2), (m_p * s_p_sq_r))                # [b, t_t, t_s]
+        neg_cent4 = torch.sum(-0.5 * (m_p ** 2) * s_p_sq_r, [1], keepdim=True)         # [b, 1, t_s]
+        return neg_cent1 + neg_cent2 + neg_cent3 + neg_cent4
+
+    def forward(self, x, x_lengths, y, y_lengths, sid=None):
+        x, m_p, logs_p, x_mask = self.enc_p(x, x_lengths)
+        g = self._speaker(sid)
+        z, m_q, logs_q, y_mask = self.enc_q(y, y_lengths, g=g)
+        z_p = self.flow(z, y_mask, g=g)
+
+        with torch.no_grad():
+            neg_cent = self.neg_cent(z_p, m_p, logs_p)
+            attn_mask = torch.unsqueeze(x_mask, 2) * torch.unsqueeze(y_mask, -1)
+            attn = K.maximum_path(neg_cent, attn_mask.squeeze(1)).unsqueeze(1).detach().to(x.dtype)
+
+        w = attn.sum(2)
+        if self.use_sdp:
+            l_length = self.dp(x, x_mask, w, g=g)
+            l_length = l_length / torch.sum(x_mask)
+        else:
+            logw_ = torch.log(w + 1e-6) * x_mask
+            logw = self.dp(x, x_mask, g=g)
+            l_length = torch.sum((logw - logw_) ** 2, [1, 2]) / torch.sum(x_mask)
+
+        # expand prior
+        m_p = torch.matmul(attn.squeeze(1), m_p.transpose(1, 2)).transpose(1, 2)
+        logs_p = torch.matmul(attn.squeeze(1), logs_p.transpose(1, 2)).transpose(1, 2)
+
+        z_slice, ids_slice = commons.rand_slice_segments(z, y_lengths, self.segment_size)
+        o = self.dec(z_slice, g=g)
+        return o, l_length, attn, ids_slice, x_mask, y_mask, (z, z_p, m_p, logs_p, m_q, logs_q)
+
+    def infer(self, x, x_lengths, sid=None, noise_scale=1, length_scale=1, noise_scale_w=1.0, max_len=None):
+        x, m_p, logs_p, x_mask = self.enc_p(x, x_lengths)
+        g = self._speaker(sid)
+        if self.use_sdp:
+            logw = self.dp(x, x_mask, g=g, reverse=True, noise_scale=noise_scale_w)
+        else:
+            logw = self.dp(x, x_mask, g=g)
+        w = torch.exp(logw) * x_mask * length_scale
+        w_ceil = torch.ceil(w)
+        y_lengths = torch.clamp_min(torch.sum(w_ceil, [1, 2]), 1).long()
+        y_mask = torch.unsqueeze(commons.sequence_mask(y_lengths, None), 1).to(x_mask.dtype)
+        attn_mask = torch.unsqueeze(x_mask, 2) * torch.unsqueeze(y_mask, -1)
+        attn = commons.generate_path(w_ceil, attn_mask)
+
+        m_p = torch.matmul(attn.squeeze(1), m_p.transpose(1, 2)).transpose(1, 2)        # [b, d, t']
+        logs_p = torch.matmul(attn.squeeze(1), logs_p.transpose(1, 2)).transpose(1, 2)
+
+        z_p = m_p + noise.randn_like(m_p) * torch.exp(logs_p) * noise_scale
+        z = self.flow(z_p, y_mask, g=g, reverse=True)
+        o = self.dec((z * y_mask)[:, :, :max_len], g=g)
+        return o, attn, y_mask, (z, z_p, m_p, logs_p)
+
+    def voice_conversion(self, y, y_lengths, sid_src, sid_tgt):
+        assert self.n_speakers > 0, "n_speakers have to be larger than 0."
+        g_src = self.emb_g(sid_src).unsqueeze(-1)
+        g_tgt = self.emb_g(sid_tgt).unsqueeze(-1)
+        z, m_q, logs_q, y_mask = self.enc_q(y, y_lengths, g=g_src)
+        z_p = self.flow(z, y_mask, g=g_src)
+        z_hat = self.flow(z_p, y_mask, g=g_tgt, reverse=True)
+        o_hat = self.dec(z_hat * y_mask, g=g_tgt)
+        return o_hat, y_mask, (z, z_p, z_hat)

@@ -1,0 +1,316 @@
+"""Building blocks of the VITS generator — mirror of the reference's modules.py (same class names,
+constructor arguments, parameter names and forward semantics), with the arithmetic routed through
+kernels.py.  File:line citations point at the reference.
+"""
+import math
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from . import commons
+from . import kernels as K
+from .commons import get_padding
+from .transforms import piecewise_rational_quadratic_transform
+
+LRELU_SLOPE = 0.1
+
+
+# ---------------------------------------------------------------------------------------------
+# Convolution modules.  The reference wraps nn.Conv1d / nn.ConvTranspose1d in the legacy
+# torch.nn.utils.weight_norm, which yields the parameters `bias`, `weight_g` [c0,1,1] and
+# `weight_v` (in that registration order).  These classes own exactly those parameters, initialise
+# them by drawing from torch's generator the way nn.Conv1d.reset_parameters does (so a seeded
+# construction consumes the same random stream), and hand them to the kernels.
+# ---------------------------------------------------------------------------------------------
+class Conv1d(nn.Module):
+    """Plain conv (parameters `weight`, `bias`), forward through kernels.conv1d."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True):
+        super().__init__()
+        proto = nn.Conv1d(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias)
+        self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, kernel_size
+        self.stride, self.padding, self.dilation, self.groups = stride, padding, dilation, groups
+        self.weight = nn.Parameter(proto.weight.data)
+        self.bias = nn.Parameter(proto.bias.data) if bias else None
+
+    def forward(self, x):
+        return K.conv1d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+
+
+class WNConv1d(nn.Module):
+    """weight_norm(Conv1d): parameters `bias`, `weight_g`, `weight_v`."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1):
+        super().__init__()
+        proto = nn.Conv1d(in_channels, out_channels, kernel_size, stride, padding, dilation, groups)
+        self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, kernel_size
+        self.stride, self.padding, self.dilation, self.groups = stride, padding, dilation, groups
+        self.bias = nn.Parameter(proto.bias.data)
+        v = proto.weight.data
+        self.weight_g = nn.Parameter(torch.linalg.vector_norm(v, 2, dim=(1, 2), keepdim=True))
+        self.weight_v = nn.Parameter(v)
+
+    @property
+    def weight(self):
+        return K.weight_norm(self.weight_v, self.weight_g)
+
+    def forward(self, x):
+        return K.conv1d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+
+
+class WNConvTranspose1d(nn.Module):
+    """weight_norm(ConvTranspose1d): weight_v is [c_in, c_out, k], the norm is per INPUT channel."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0):
+        super().__init__()
+        proto = nn.ConvTranspose1d(in_channels, out_channels, kernel_size, stride, padding)
+        self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, kernel_size
+        self.stride, self.padding = stride, padding
+        self.bias = nn.Parameter(proto.bias.data)
+        v = proto.weight.data
+        self.weight_g = nn.Parameter(torch.linalg.vector_norm(v, 2, dim=(1, 2), keepdim=True))
+        self.weight_v = nn.Parameter(v)
+
+    @property
+    def weight(self):
+        return K.weight_norm(self.weight_v, self.weight_g)
+
+    def forward(self, x):
+        return K.conv_transpose1d(x, self.weight, self.bias, self.stride, self.padding)
+
+
+def _burn_init_weights(module_list):
+    """The reference calls `.apply(init_weights)` on weight-normed convs (models.py:265,
+    modules.py:199,209,240).  With legacy weight_norm that only overwrites the derived `weight`
+    attribute, which the next forward recomputes from weight_g/weight_v — the parameters keep
+    their default init, but the call does consume numel(weight) normal draws per conv.  Draw the
+    same amount so a seeded construction stays aligned with the reference's random stream."""
+    for m in module_list:
+        torch.empty_like(m.weight_v).normal_(0.0, 0.01)
+
+
+class LayerNorm(nn.Module):
+    # modules.py:20-32 — normalises the channel dim of [b, c, t]
+    def __init__(self, channels, eps=1e-5):
+        super().__init__()
+        self.channels = channels
+        self.eps = eps
+        self.gamma = nn.Parameter(torch.ones(channels))
+        self.beta = nn.Parameter(torch.zeros(channels))
+
+    def forward(self, x):
+        return K.layer_norm_c(x, self.gamma, self.beta, self.eps)
+
+
+class DDSConv(nn.Module):
+    """Dilated and depth-separable convolution (modules.py:70-108)."""
+
+    def __init__(self, channels, kernel_size, n_layers, p_dropout=0.0):
+        super().__init__()
+        self.channels, self.kernel_size, self.n_layers, self.p_dropout = channels, kernel_size, n_layers, p_dropout
+        self.drop = nn.Dropout(p_dropout)
+        self.convs_sep = nn.ModuleList()
+        self.convs_1x1 = nn.ModuleList()
+        self.norms_1 = nn.ModuleList()
+        self.norms_2 = nn.ModuleList()
+        for i in range(n_layers):
+            dilation = kernel_size ** i
+            padding = (kernel_size * dilation - dilation) // 2
+            self.convs_sep.append(Conv1d(channels, channels, kernel_size, groups=channels, dilation=dilation, padding=padding))
+            self.convs_1x1.append(Conv1d(channels, channels, 1))
+            self.norms_1.append(LayerNorm(channels))
+            self.norms_2.append(LayerNorm(channels))
+
+    def forward(self, x, x_mask, g=None):
+        if g is not None:
+            x = x + g
+        for i in range(self.n_layers):
+            y = self.convs_sep[i](x * x_mask)
+            y = F.gelu(self.norms_1[i](y))
+            y = self.convs_1x1[i](y)
+            y = F.gelu(self.norms_2[i](y))
+            y = self.drop(y)
+            x = x + y
+        return x * x_mask
+
+
+class WN(nn.Module):
+    """Gated WaveNet stack (modules.py:111-184)."""
+
+    def __init__(self, hidden_channels, kernel_size, dilation_rate, n_layers, gin_channels=0, p_dropout=0):
+        super().__init__()
+        assert kernel_size % 2 == 1
+        self.hidden_channels = hidden_channels
+        self.kernel_size = (kernel_size,)
+        self.dilation_rate, self.n_layers, self.gin_channels, self.p_dropout = dilation_rate, n_layers, gin_channels, p_dropout
+        self.in_layers = nn.ModuleList()
+        self.res_skip_layers = nn.ModuleList()
+        self.drop = nn.Dropout(p_dropout)
+        if gin_channels != 0:
+            self.cond_layer = WNConv1d(gin_channels, 2 * hidden_channels * n_layers, 1)
+        for i in range(n_layers):
+            dilation = dilation_rate ** i
+            padding = int((kernel_size * dilation - dilation) / 2)
+            self.in_layers.append(WNConv1d(hidden_channels, 2 * hidden_channels, kernel_size, dilation=dilation, padding=padding))
+            res_skip_channels = 2 * hidden_channels if i < n_layers - 1 else hidden_channels
+            self.res_skip_layers.append(WNConv1d(hidden_channels, res_skip_channels, 1))
+
+    def forward(self, x, x_mask, g=None, **kwargs):
+        H = self.hidden_channels
+        output = None
+        if g is not None:
+            g = self.cond_layer(g)                                     # [b, 2*H*L, 1]
+        for i in range(self.n_layers):
+            x_in = self.in_layers[i](x)
+            g_l = g[:, i * 2 * H:(i + 1) * 2 * H, :] if g is not None else None
+            acts = self.drop(K.wn_gate(x_in, g_l, H))
+            res_skip = self.res_skip_layers[i](acts)
+            if i < self.n_layers - 1:
+                x = (x + res_skip[:, :H, :]) * x_mask
+                skip = res_skip[:, H:, :]
+            else:
+                skip = res_skip
+            output = skip if output is None else output + skip
+        return output * x_mask
+
+
+class ResBlock1(nn.Module):
+    # modules.py:187-229
+    def __init__(self, channels, kernel_size=3, dilation=(1, 3, 5)):
+        super().__init__()
+        self.convs1 = nn.ModuleList([
+            WNConv1d(channels, channels, kernel_size, 1, dilation=d, padding=get_padding(kernel_size, d)) for d in dilation])
+        _burn_init_weights(self.convs1)
+        self.convs2 = nn.ModuleList([
+            WNConv1d(channels, channels, kernel_size, 1, dilation=1, padding=get_padding(kernel_size, 1)) for _ in dilation])
+        _burn_init_weights(self.convs2)
+
+    def forward(self, x, x_mask=None):
+        for c1, c2 in zip(self.convs1, self.convs2):
+            xt = K.leaky_relu(x, LRELU_SLOPE)
+            if x_mask is not None:
+                xt = xt * x_mask
+            xt = c1(xt)
+            xt = K.leaky_relu(xt, LRELU_SLOPE)
+            if x_mask is not None:
+                xt = xt * x_mask
+            xt = c2(xt)
+            x = xt + x
+        if x_mask is not None:
+            x = x * x_mask
+        return x
+
+
+class ResBlock2(nn.Module):
+    # modules.py:232-256
+    def __init__(self, channels, kernel_size=3, dilation=(1, 3)):
+        super().__init__()
+        self.convs = nn.ModuleList([
+            WNConv1d(channels, channels, kernel_size, 1, dilation=d, padding=get_padding(kernel_size, d)) for d in dilation])
+        _burn_init_weights(self.convs)
+
+    def forward(self, x, x_mask=None):
+        for c in self.convs:
+            xt = K.leaky_relu(x, LRELU_SLOPE)
+            if x_mask is not None:
+                xt = xt * x_mask
+            xt = c(xt)
+            x = xt + x
+        if x_mask is not None:
+            x = x * x_mask
+        return x
+
+
+class Log(nn.Module):
+    # modules.py:259-267
+    def forward(self, x, x_mask, reverse=False, **kwargs):
+        if not reverse:
+            y = torch.log(torch.clamp_min(x, 1e-5)) * x_mask
+            return y, torch.sum(-y, [1, 2])
+        return torch.exp(x) * x_mask
+
+
+class Flip(nn.Module):
+    # modules.py:270-277
+    def forward(self, x, *args, reverse=False, **kwargs):
+        x = torch.flip(x, [1])
+        if not reverse:
+            return x, torch.zeros(x.size(0), dtype=x.dtype, device=x.device)
+        return x
+
+
+class ElementwiseAffine(nn.Module):
+    # modules.py:280-295
+    def __init__(self, channels):
+        super().__init__()
+        self.channels = channels
+        self.m = nn.Parameter(torch.zeros(channels, 1))
+        self.logs = nn.Parameter(torch.zeros(channels, 1))
+
+    def forward(self, x, x_mask, reverse=False, **kwargs):
+        if not reverse:
+            y = (self.m + torch.exp(self.logs) * x) * x_mask
+            return y, torch.sum(self.logs * x_mask, [1, 2])
+        return (x - self.m) * torch.exp(-self.logs) * x_mask
+
+
+class ResidualCouplingLayer(nn.Module):
+    # modules.py:298-343
+    def __init__(self, channels, hidden_channels, kernel_size, dilation_rate, n_layers, p_dropout=0, gin_channels=0, mean_only=False):
+        assert channels % 2 == 0, "channels should be divisible by 2"
+        super().__init__()
+        self.channels, self.hidden_channels, self.kernel_size = channels, hidden_channels, kernel_size
+        self.dilation_rate, self.n_layers = dilation_rate, n_layers
+        self.half_channels = channels // 2
+        self.mean_only = mean_only
+        self.pre = Conv1d(self.half_channels, hidden_channels, 1)
+        self.enc = WN(hidden_channels, kernel_size, dilation_rate, n_layers, p_dropout=p_dropout, gin_channels=gin_channels)
+        self.post = Conv1d(hidden_channels, self.half_channels * (2 - mean_only), 1)
+        self.post.weight.data.zero_()
+        self.post.bias.data.zero_()
+
+    def forward(self, x, x_mask, g=None, reverse=False):
+        x0, x1 = torch.split(x, [self.half_channels] * 2, 1)
+        h = self.pre(x0) * x_mask
+        h = self.enc(h, x_mask, g=g)
+        stats = self.post(h) * x_mask
+        if not self.mean_only:
+            m, logs = torch.split(stats, [self.half_channels] * 2, 1)
+        else:
+            m, logs = stats, torch.zeros_like(stats)
+        if not reverse:
+            x1 = m + x1 * torch.exp(logs) * x_mask
+            return torch.cat([x0, x1], 1), torch.sum(logs, [1, 2])
+        x1 = (x1 - m) * torch.exp(-logs) * x_mask
+        return torch.cat([x0, x1], 1)
+
+
+class ConvFlow(nn.Module):
+    # modules.py:346-390
+    def __init__(self, in_channels, filter_channels, kernel_size, n_layers, num_bins=10, tail_bound=5.0):
+        super().__init__()
+        self.in_channels, self.filter_channels, self.kernel_size, self.n_layers = in_channels, filter_channels, kernel_size, n_layers
+        self.num_bins, self.tail_bound = num_bins, tail_bound
+        self.half_channels = in_channels // 2
+        self.pre = Conv1d(self.half_channels, filter_channels, 1)
+        self.convs = DDSConv(filter_channels, kernel_size, n_layers, p_dropout=0.0)
+        self.proj = Conv1d(filter_channels, self.half_channels * (num_bins * 3 - 1), 1)
+        self.proj.weight.data.zero_()
+        self.proj.bias.data.zero_()
+
+    def forward(self, x, x_mask, g=None, reverse=False):
+        x0, x1 = torch.split(x, [self.half_channels] * 2, 1)
+        h = self.pre(x0)
+        h = self.convs(h, x_mask, g=g)
+        h = self.proj(h) * x_mask
+        b, c, t = x0.shape
+        h = h.reshape(b, c, -1, t).permute(0, 1, 3, 2)                 # [b, c, t, 3*bins-1]
+        uw = h[..., :self.num_bins] / math.sqrt(self.filter_channels)
+        uh = h[..., self.num_bins:2 * self.num_bins] / math.sqrt(self.filter_channels)
+        ud = h[..., 2 * self.num_bins:]
+        x1, logabsdet = piecewise_rational_quadratic_transform(x1, uw, uh, ud, inverse=reverse, tails="linear", tail_bound=self.tail_bound)
+        x = torch.cat([x0, x1.to(x0.dtype)], 1) * x_mask
+        if not reverse:
+            return x, torch.sum(logabsdet * x_mask, [1, 2])
+        return x

@@ -26,9 +26,11 @@ def maximum_path_lengths(neg_cent, t_ys, t_xs, out_dtype=None, status=None):
     path = torch.empty((b, t_t, t_s), device=nc.device, dtype=out_dtype if kernel_dtype is not None else torch.float32)
     t_ys = t_ys.to(torch.int32).contiguous()
     t_xs = t_xs.to(torch.int32).contiguous()
+    e0 = _lib.timer.start("vits_mas_f32")
     rc = _lib.lib().vits_mas_f32(nc.data_ptr(), path.data_ptr(), kernel_dtype if kernel_dtype is not None else 0,
                                  t_ys.data_ptr(), t_xs.data_ptr(), b, t_t, t_s,
                                  status.data_ptr() if status is not None else None, _lib.stream_ptr())
+    _lib.timer.stop("vits_mas_f32", e0, b * t_t * t_s)       # units = DP cells
     _lib.check(rc, "vits_mas_f32")
     return path if kernel_dtype is not None else path.to(out_dtype)
 

@@ -1,0 +1,142 @@
+"""The fine-tune step — mirror of reference finetune_speaker_v2.py:174-232 (one iteration of
+train_and_evaluate's hot loop): G forward, mel targets, D step, G step, two AdamW updates.
+
+Differences from the reference, none of which changes a result:
+  * bf16 autocast instead of fp16 autocast + GradScaler (no loss scaling needed); `amp=False`
+    runs everything in fp32 (the parity mode);
+  * gradients are reduced through distributed.GradBuckets (overlapped flat all-reduce) instead
+    of two DDP wrappers, and D's parameters do not take gradients during the G step (the
+    reference computes and all-reduces them there only to zero them at the next iteration,
+    finetune_speaker_v2.py:210,218,228);
+  * grad norms are 0-d tensors (commons.grad_norm_l2), discriminator_loss keeps tensors: no
+    host synchronisation inside the step.
+"""
+import contextlib
+
+import torch
+from torch.nn import functional as F
+
+from . import commons
+from .distributed import GradBuckets, broadcast_parameters
+from .losses import discriminator_loss, feature_loss, generator_loss, kl_loss
+from .mel_processing import mel_spectrogram_torch, spec_to_mel_torch
+from .models import MultiPeriodDiscriminator, SynthesizerTrn
+
+
+class FineTuner:
+    def __init__(self, hps, device, amp=True, bucket_bytes=64 << 20):
+        self.hps, self.device, self.amp = hps, torch.device(device), amp
+        torch.manual_seed(hps.train.seed)                       # finetune_speaker_v2.py:70
+        m = {k: v for k, v in hps.model.items()}
+        self.net_g = SynthesizerTrn(hps.n_symbols, hps.data.filter_length // 2 + 1,
+                                    hps.train.segment_size // hps.data.hop_length,
+                                    n_speakers=hps.data.n_speakers, **m).to(self.device)
+        self.net_d = MultiPeriodDiscriminator(hps.model.use_spectral_norm).to(self.device)
+        broadcast_parameters(self.net_g)
+        broadcast_parameters(self.net_d)
+        fused = self.device.type == "cuda"
+        self.optim_g = torch.optim.AdamW(self.net_g.parameters(), hps.train.learning_rate, betas=hps.train.betas,
+                                         eps=hps.train.eps, fused=fused)
+        self.optim_d = torch.optim.AdamW(self.net_d.parameters(), hps.train.learning_rate, betas=hps.train.betas,
+                                         eps=hps.train.eps, fused=fused)
+        self.buckets_g = GradBuckets(self.net_g.parameters(), bucket_bytes)
+        self.buckets_d = GradBuckets(self.net_d.parameters(), bucket_bytes)
+        self.sched_g = torch.optim.lr_scheduler.ExponentialLR(self.optim_g, gamma=hps.train.lr_decay)
+        self.sched_d = torch.optim.lr_scheduler.ExponentialLR(self.optim_d, gamma=hps.train.lr_decay)
+        self.net_g.train()
+        self.net_d.train()
+
+    def _autocast(self):
+        if self.amp and self.device.type == "cuda":
+            return torch.autocast("cuda", dtype=torch.bfloat16)
+        return contextlib.nullcontext()
+
+    def step(self, batch):
+        """batch = (x, x_lengths, spec, spec_lengths, y, y_lengths, speakers), already on the device."""
+        hps = self.hps
+        x, x_lengths, spec, spec_lengths, y, y_lengths, speakers = batch
+        seg_frames = hps.train.segment_size // hps.data.hop_length
+
+        with self._autocast():
+            y_hat, l_length, attn, ids_slice, x_mask, z_mask, (z, z_p, m_p, logs_p, m_q, logs_q) = \
+                self.net_g(x, x_lengths, spec, spec_lengths, speakers)
+            mel = spec_to_mel_torch(spec.float(), hps.data.filter_length, hps.data.n_mel_channels, hps.data.sampling_rate,
+                                    hps.data.mel_fmin, hps.data.mel_fmax)
+            y_mel = commons.slice_segments(mel, ids_slice, seg_frames)
+            y_hat_mel = mel_spectrogram_torch(y_hat.squeeze(1), hps.data.filter_length, hps.data.n_mel_channels,
+                                              hps.data.sampling_rate, hps.data.hop_length, hps.data.win_length,
+                                              hps.data.mel_fmin, hps.data.mel_fmax)
+            y = commons.slice_segments(y, ids_slice * hps.data.hop_length, hps.train.segment_size)
+
+            # ---- discriminator step (finetune_speaker_v2.py:205-214)
+            y_d_hat_r, y_d_hat_g, _, _ = self.net_d(y, y_hat.detach())
+        loss_disc, losses_disc_r, losses_disc_g = discriminator_loss(y_d_hat_r, y_d_hat_g)
+        self.buckets_d.zero_grad()
+        loss_disc.backward()
+        self.buckets_d.finish()
+        grad_norm_d = commons.grad_norm_l2(self.net_d.parameters())
+        self.optim_d.step()
+
+        # ---- generator step (finetune_speaker_v2.py:216-232); D already updated (its fmaps come
+        #      from the new weights, as in the reference) and frozen for this backward
+        for p in self.net_d.parameters():
+            p.requires_grad_(False)
+        self.buckets_d.enabled(False)
+        try:
+            with self._autocast():
+                y_d_hat_r, y_d_hat_g, fmap_r, fmap_g = self.net_d(y, y_hat)
+            loss_dur = torch.sum(l_length.float())
+            loss_mel = F.l1_loss(y_mel.float(), y_hat_mel.float()) * hps.train.c_mel
+            loss_kl = kl_loss(z_p, logs_q, m_p, logs_p, z_mask) * hps.train.c_kl
+            loss_fm = feature_loss(fmap_r, fmap_g)
+            loss_gen, losses_gen = generator_loss(y_d_hat_g)
+            loss_gen_all = loss_gen + loss_fm + loss_mel + loss_dur + loss_kl
+            self.buckets_g.zero_grad()
+            loss_gen_all.backward()
+        finally:
+            for p in self.net_d.parameters():
+                p.requires_grad_(True)
+            self.buckets_d.enabled(True)
+        self.buckets_g.finish()
+        grad_norm_g = commons.grad_norm_l2(self.net_g.parameters())
+        self.optim_g.step()
+
+        return dict(loss_disc=loss_disc.detach(), loss_gen=loss_gen.detach(), loss_fm=loss_fm.detach(),
+                    loss_mel=loss_mel.detach(), loss_dur=loss_dur.detach(), loss_kl=loss_kl.detach(),
+                    grad_norm_d=grad_norm_d, grad_norm_g=grad_norm_g)
+
+    def epoch_end(self):
+        self.sched_g.step()            # ExponentialLR per epoch, finetune_speaker_v2.py:157-158
+        self.sched_d.step()
+
+
+def synthetic_batch(hps, batch_size, t_y_range, device, seed=1234, rank=0):
+    """Deterministic synthetic minibatch of SURVEY.md §8(d): lengths linspace(lo, hi) sorted
+    descending (TextAudioSpeakerCollate, data_utils.py:129-131), text ids with interspersed blanks
+    (commons.py:24-27, T_x = 2n+1), waveforms = 3 sinusoids + noise peak-normalised to 0.5,
+    spec = spectrogram_torch(wav), speaker ids round-robin."""
+    from .mel_processing import spectrogram_torch
+    gen = torch.Generator().manual_seed(seed + 1000 * rank)
+    lo, hi = t_y_range
+    hop = hps.data.hop_length
+    t_y = torch.linspace(lo, hi, batch_size).round().long().flip(0)
+    n_tok = torch.round(t_y / 5).long()
+    t_x = 2 * n_tok + 1
+    B, T_x, T_y = batch_size, int(t_x.max()), int(t_y.max())
+    x = torch.zeros(B, T_x, dtype=torch.long)
+    for i in range(B):
+        ids = torch.randint(1, hps.n_symbols, (int(n_tok[i]),), generator=gen)
+        x[i, 1:2 * int(n_tok[i]):2] = ids
+    wav = torch.zeros(B, T_y * hop)
+    tt = torch.arange(T_y * hop) / hps.data.sampling_rate
+    for i in range(B):
+        n = int(t_y[i]) * hop
+        f = torch.rand(3, generator=gen) * 3920 + 80
+        w = sum(torch.sin(2 * torch.pi * f[k] * tt[:n] + k) for k in range(3)) + torch.randn(n, generator=gen) * 0.01
+        wav[i, :n] = 0.5 * w / w.abs().max()
+    sid = torch.arange(B) % min(hps.data.n_speakers, 10)
+    wav = wav.to(device)
+    spec = spectrogram_torch(wav, hps.data.filter_length, hps.data.sampling_rate, hop, hps.data.win_length)
+    frame = torch.arange(T_y, device=device)[None, :] < t_y.to(device)[:, None]
+    spec = spec * frame[:, None, :]
+    return (x.to(device), t_x.to(device), spec, t_y.to(device), wav.unsqueeze(1), (t_y * hop).to(device), sid.to(device))
