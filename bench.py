@@ -46,11 +46,9 @@ def cpu_baseline(hps, cfgs, seconds_budget=25.0):
     opt_g = torch.optim.AdamW([v for v in sd_g.values() if v.requires_grad], hps.train.learning_rate, betas=hps.train.betas, eps=hps.train.eps)
     opt_d = torch.optim.AdamW(list(sd_d.values()), hps.train.learning_rate, betas=hps.train.betas, eps=hps.train.eps)
     B = 2
-    # the product's synthetic-batch maker needs the HIP-free spectrogram: build the batch with the oracle's
-    x, x_len, _, t_y, wav, wav_len, sid = tr.synthetic_batch.__wrapped__(hps, B, (96, 120), "cpu") if hasattr(tr.synthetic_batch, "__wrapped__") else tr.synthetic_batch(hps, B, (96, 120), "cpu")
-    spec = O.spectrogram(wav.squeeze(1), hps.data.filter_length, hps.data.hop_length, hps.data.win_length)
-    spec = spec * (torch.arange(spec.size(2))[None, :] < t_y[:, None])[:, None, :]
-    batch = (x, x_len, spec, t_y, wav, wav_len, sid)
+    batch = tr.synthetic_batch(hps, B, (96, 120), "cpu",
+                               spec_fn=lambda w: O.spectrogram(w, hps.data.filter_length, hps.data.hop_length, hps.data.win_length))
+    x, spec = batch[0], batch[2]
     hp = dict(hps.data); hp.update(hps.train)
     H, T_x = hps.model.hidden_channels, x.size(1)
     steps, t_total = 0, 0.0
@@ -106,14 +104,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    trace = os.environ.get("VITS_BENCH_TRACE") == "1"      # debugging aid: sync + log every step
+    for i in range(args.warmup):
         out = tuner.step(batch)
+        if trace:
+            torch.cuda.synchronize()
+            bad = [n for n, q in list(tuner.net_g.named_parameters()) + list(tuner.net_d.named_parameters()) if not torch.isfinite(q).all()]
+            print(f"warmup {i} ok", {k: round(float(v), 4) for k, v in out.items()}, "non-finite params:", bad[:4], file=sys.stderr, flush=True)
     P._lib.timer.enabled = True
     P._lib.timer.reset()
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         out = tuner.step(batch)
+        if trace:
+            torch.cuda.synchronize(); print(f"step {i} ok", file=sys.stderr, flush=True)
     sync()
     elapsed = time.perf_counter() - t0
     P._lib.timer.enabled = False

@@ -220,6 +220,18 @@ class Generator(nn.Module):
         raise NotImplementedError("weight-norm folding for inference is SURVEY §8 (f-2), not built yet")
 
 
+def _first_layer_fp32(layer, x):
+    """The single-input-channel first convolution of each discriminator runs in fp32 even under
+    bf16 autocast: MIOpen's bf16 backward-data solver for c_in = 1 (e.g. `convbfp16 -n 32 -c 1 -W 8192
+    -k 16 -x 15 -F 2`) faults on gfx950/ROCm 7.2 from its third invocation on (found with
+    MIOPEN_ENABLE_LOGGING_CMD=1 + AMD_SERIALIZE_KERNEL=3).  With one input channel the layer is
+    <0.1 % of the discriminator's FLOPs, and fp32 is at least the reference's precision."""
+    if torch.is_autocast_enabled():
+        with torch.autocast("cuda", enabled=False):
+            return layer(x.float())
+    return layer(x)
+
+
 class _WNConv2dK1(nn.Module):
     """weight_norm(Conv2d(cin, cout, (k,1), (s,1), padding=(p,0))) of DiscriminatorP (models.py:304-312);
     parameters `bias`, `weight_g` [cout,1,1,1], `weight_v` [cout,cin,k,1]."""
@@ -261,8 +273,8 @@ class DiscriminatorP(nn.Module):
             x = F.pad(x, (0, n_pad), "reflect")
             t = t + n_pad
         x = x.view(b, c, t // self.period, self.period)
-        for l in self.convs:
-            x = F.leaky_relu(l(x), modules.LRELU_SLOPE)
+        for i, l in enumerate(self.convs):
+            x = F.leaky_relu(_first_layer_fp32(l, x) if i == 0 else l(x), modules.LRELU_SLOPE)
             fmap.append(x)
         x = self.conv_post(x)
         fmap.append(x)
@@ -283,8 +295,8 @@ class DiscriminatorS(nn.Module):
 
     def forward(self, x):
         fmap = []
-        for l in self.convs:
-            x = F.leaky_relu(l(x), modules.LRELU_SLOPE)
+        for i, l in enumerate(self.convs):
+            x = F.leaky_relu(_first_layer_fp32(l, x) if i == 0 else l(x), modules.LRELU_SLOPE)
             fmap.append(x)
         x = self.conv_post(x)
         fmap.append(x)

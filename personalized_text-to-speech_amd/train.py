@@ -110,12 +110,14 @@ class FineTuner:
         self.sched_d.step()
 
 
-def synthetic_batch(hps, batch_size, t_y_range, device, seed=1234, rank=0):
+def synthetic_batch(hps, batch_size, t_y_range, device, seed=1234, rank=0, spec_fn=None):
     """Deterministic synthetic minibatch of SURVEY.md §8(d): lengths linspace(lo, hi) sorted
     descending (TextAudioSpeakerCollate, data_utils.py:129-131), text ids with interspersed blanks
     (commons.py:24-27, T_x = 2n+1), waveforms = 3 sinusoids + noise peak-normalised to 0.5,
     spec = spectrogram_torch(wav), speaker ids round-robin."""
-    from .mel_processing import spectrogram_torch
+    if spec_fn is None:
+        from .mel_processing import spectrogram_torch
+        spec_fn = lambda w: spectrogram_torch(w, hps.data.filter_length, hps.data.sampling_rate, hps.data.hop_length, hps.data.win_length)
     gen = torch.Generator().manual_seed(seed + 1000 * rank)
     lo, hi = t_y_range
     hop = hps.data.hop_length
@@ -136,7 +138,7 @@ def synthetic_batch(hps, batch_size, t_y_range, device, seed=1234, rank=0):
         wav[i, :n] = 0.5 * w / w.abs().max()
     sid = torch.arange(B) % min(hps.data.n_speakers, 10)
     wav = wav.to(device)
-    spec = spectrogram_torch(wav, hps.data.filter_length, hps.data.sampling_rate, hop, hps.data.win_length)
+    spec = spec_fn(wav)
     frame = torch.arange(T_y, device=device)[None, :] < t_y.to(device)[:, None]
     spec = spec * frame[:, None, :]
     return (x.to(device), t_x.to(device), spec, t_y.to(device), wav.unsqueeze(1), (t_y * hop).to(device), sid.to(device))
