@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Steady-state per-step kernel summary from a rocprofv3 --kernel-trace CSV.
+
+The fine-tune step launches the alignment kernel (mas_kernel) exactly once, so consecutive
+mas_kernel start times delimit one step.  The last `--steps` such windows are aggregated by
+kernel name: calls/step, total and average duration, share of the step's kernel time.
+usage: prof_summary.py <kernel_trace.csv> [--steps 3] [--top 40] [--marker mas_kernel]
+"""
+import argparse
+import collections
+import csv
+import sys
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("trace")
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--top", type=int, default=40)
+    ap.add_argument("--marker", default="mas_kernel")
+    a = ap.parse_args()
+    rows = []
+    with open(a.trace) as f:
+        for r in csv.DictReader(f):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+    rows.sort()
+    marks = [i for i, r in enumerate(rows) if a.marker in r[2]]
+    if len(marks) < a.steps + 1:
+        sys.exit(f"only {len(marks)} marker launches")
+    lo, hi = marks[-a.steps - 1], marks[-1]
+    win = rows[lo:hi]
+    wall = (rows[hi][0] - rows[lo][0]) / a.steps
+    agg = collections.defaultdict(lambda: [0, 0])
+    for s, e, n in win:
+        agg[n][0] += 1
+        agg[n][1] += e - s
+    busy = sum(v[1] for v in agg.values()) / a.steps
+    print(f"# steady-state window: {a.steps} steps, wall {wall/1e6:.3f} ms/step, kernel-busy {busy/1e6:.3f} ms/step, "
+          f"{len(win)/a.steps:.0f} launches/step, {len(agg)} distinct kernels")
+    print(f"# {'ms/step':>9} {'share':>7} {'calls/step':>10} {'avg_us':>9}  kernel")
+    for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[: a.top]:
+        print(f"  {t/a.steps/1e6:9.3f} {100*t/a.steps/busy:6.2f}% {c/a.steps:10.1f} {t/c/1e3:9.1f}  {n[:120]}")
+
+
+if __name__ == "__main__":
+    main()
