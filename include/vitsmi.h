@@ -65,6 +65,53 @@ int vits_mas_f32(const float* neg_cent, void* path, int path_dtype,
                  const int32_t* t_ys, const int32_t* t_xs,
                  int b, int t_t, int t_s, int32_t* status, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Channels-last 1-D convolution, stride 1, on the matrix cores (forward and data gradient).
+ *
+ * Replaces: every stride-1 torch.nn.Conv1d call of the generator — modules.py:211-223 (ResBlock1),
+ *           :240-250 (ResBlock2), :157-172 (WN in_layers / res_skip_layers), attentions.py:286-293
+ *           (FFN), models.py:271-273,286 (conv_pre, cond, conv_post), the 1x1 pre/post/proj layers
+ *           (models.py:231-238, modules.py:321-328) — together with the element-wise ops the
+ *           reference runs around them (F.leaky_relu before the conv, `+ x` residual, `* x_mask`,
+ *           `xs / num_kernels`, tanh), which are fused here as prologue / epilogue.
+ *
+ *   x      [b][t][c_in]      activations, channels last (the reference holds [b, c, t])
+ *   w      [k][c_out][c_in]  weights, tap-major (reference Conv1d.weight is [c_out, c_in, k])
+ *   y      [b][t_out][c_out], t_out = t + 2*pad - dil*(k-1)
+ *   Y[b,t,co] = f( scale * ( sum_{tap,ci} w[tap,co,ci] * lrelu_{in_slope}(x[b, t+tap*dil-pad, ci])
+ *                            + bias[co] + bias_b[b,co] + res[b,t,co] ) )
+ *   bias   float32[c_out] or NULL;   bias_b float32[b][c_out] or NULL (per-item conditioning);
+ *   res    [b][t_out][c_out] or NULL (same dtype as x);
+ *   mg_src [b][t_out][c_out] or NULL: multiply the result by lrelu'_{mg_slope}(mg_src) — the chain
+ *          rule of a fused input activation when this call computes a data gradient;
+ *   lengths int32[b] (valid rows per item) — needed by VITS_CONV_MASK_IN / _MASK_OUT;
+ *   in_slope = 1 disables the input activation.  dtype: VITS_DT_BF16 (c_in % 8 == 0, fp32
+ *   accumulate) or VITS_DT_F32 (c_in % 4 == 0; exact fp32 fmaf chain on the matrix core).
+ * The data gradient of a convolution is the same call on dY with w' [k][c_in][c_out],
+ * w'[tap][ci][co] = w[k-1-tap][co][ci], and pad' = dil*(k-1) - pad.
+ * ------------------------------------------------------------------------------------------ */
+#define VITS_CONV_MASK_IN   1   /* rows t >= lengths[b] of x read as zero  (x * x_mask before the conv) */
+#define VITS_CONV_MASK_OUT  2   /* rows t >= lengths[b] of y written as zero ((...) * x_mask after)     */
+#define VITS_CONV_TANH      4   /* y = tanh(.)                                                          */
+#define VITS_CONV_ACCUM     8   /* y += result                                                          */
+int vits_conv1d_cl(int dtype, const void* x, const void* w, const float* bias, const float* bias_b,
+                   const void* res, const void* mg_src, void* y, const int32_t* lengths,
+                   int b, int t, int c_in, int c_out, int k, int dil, int pad,
+                   float in_slope, float mg_slope, float out_scale, int flags, void* stream);
+
+/* Weight gradient of vits_conv1d_cl (same x, lengths, in_slope, MASK flags as the forward call):
+ *   dw[tap][co][ci] (+)= sum_{b,t} dy[b][t][co] * lrelu_{in_slope}(x[b][t + tap*dil - pad][ci])
+ * Replaces the weight half of autograd's conv1d backward for the layers listed above.
+ *   dy [b][t_out][c_out] (dtype of x);  dw float32 [k][c_out][c_in];  k in {1,3,5,7,11};
+ *   workspace: device scratch of at least vits_conv1d_cl_wgrad_workspace(...) bytes (per-split fp32
+ *   slabs, summed in a fixed order: results are bitwise reproducible);
+ *   flags: VITS_CONV_MASK_IN (x rows >= lengths[b] are zero), VITS_CONV_MASK_OUT (dy rows >=
+ *   lengths[b] are zero), VITS_CONV_ACCUM (add to dw instead of overwriting). */
+size_t vits_conv1d_cl_wgrad_workspace(int b, int t_out, int c_in, int c_out, int k);
+int vits_conv1d_cl_wgrad(int dtype, const void* x, const void* dy, float* dw, void* workspace,
+                         size_t workspace_bytes, const int32_t* lengths, int b, int t, int c_in, int c_out,
+                         int k, int dil, int pad, float in_slope, int flags, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

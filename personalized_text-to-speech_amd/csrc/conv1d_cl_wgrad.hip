@@ -1,0 +1,246 @@
+// Weight gradient of the channels-last 1-D convolution (csrc/conv1d_cl.hip) on the matrix cores.
+//
+//   dW[tap][co][ci] = sum_{b,t} dY[b][t][co] * act(X[b][t + tap*dil - pad][ci])
+//
+// GEMM view: M = co, N = ci, reduction = (b, t).  Both operands are reduced over their ROW index
+// in the channels-last tiles, which is exactly what the MFMA wants once the tile is read
+// column-wise:
+//   bf16 : ds_read_b64_tr_b16 (gfx950's transposing LDS read) turns a 4(t) x 16(c) block into
+//          per-lane columns — two reads make one 8-deep v_mfma_f32_32x32x16_bf16 fragment, and a
+//          tap is a row offset of the X tile (any shift: only the COLUMN offset must be 8-byte
+//          aligned, and it is);
+//   f32  : v_mfma_f32_32x32x2_f32 takes one k per lane, so lane (i, h) simply reads row 2s+h,
+//          column i: a conflict-free ds_read_b32.
+// Workgroup = 4 waves = 64 co x 64 ci x all taps (wave (i,j) owns the 32x32 block (i,j) and one
+// accumulator per tap).  The (b, t) reduction is split over blockIdx.x; every split writes its own
+// fp32 slab and a second kernel sums the slabs in a fixed order (bitwise reproducible — no float
+// atomics, cdna_hip_programming.md Guideline 12).
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TK = 128;          // time rows per staged chunk
+constexpr int CT = 64;           // channels per tile (both co and ci)
+constexpr int kThreads = 256;
+
+struct WgradArgs {
+  const void* x; const void* dy; float* partial; const int* lengths;
+  int B, T, Tout, Cin, Cout, K, dil, pad, S, chunks_per_item;
+  float in_slope;
+  int flags;
+};
+
+__device__ __forceinline__ float to_f(float v) { return v; }
+__device__ __forceinline__ float to_f(__bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ __bf16 from_f<__bf16>(float v) { return (__bf16)v; }
+
+template <typename T>
+__device__ __forceinline__ u32x4 lrelu_vec(u32x4 raw, float slope) {
+  constexpr int V = 16 / sizeof(T);
+  union { u32x4 u; T e[V]; } in, out;
+  in.u = raw;
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    float f = to_f(in.e[i]);
+    out.e[i] = from_f<T>(f > 0.f ? f : f * slope);
+  }
+  return out.u;
+}
+
+template <typename T> struct Pitch;
+template <> struct Pitch<__bf16> { static constexpr int value = CT * 2 + 64; };   // 192 B: tr-reads conflict-free
+template <> struct Pitch<float> { static constexpr int value = CT * 4 + 16; };
+
+template <typename T, int KT>
+__global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int V = 16 / sizeof(T);
+  constexpr int PITCH = Pitch<T>::value;
+  constexpr int VPR = CT / V;                 // 16-byte vectors per tile row
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wi = wave >> 1, wj = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int co0 = blockIdx.y * CT, ci0 = blockIdx.z * CT;
+  const int xrows = TK + (KT - 1) * a.dil;
+  unsigned char* ldsD = smem;                               // [TK][CT] of dY
+  unsigned char* ldsX = smem + (size_t)TK * PITCH;          // [xrows][CT] of act(X)
+
+  f32x16 acc[KT];
+#pragma unroll
+  for (int k = 0; k < KT; ++k)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
+
+  const int n_chunks = a.B * a.chunks_per_item;
+  for (int ch = blockIdx.x; ch < n_chunks; ch += a.S) {
+    const int b = ch / a.chunks_per_item;
+    const int t0 = (ch % a.chunks_per_item) * TK;
+    const int len = a.lengths ? a.lengths[b] : a.T;
+    const int t_out_hi = (a.flags & VITS_CONV_MASK_OUT) ? (len < a.Tout ? len : a.Tout) : a.Tout;
+    const int t_in_hi = (a.flags & VITS_CONV_MASK_IN) ? (len < a.T ? len : a.T) : a.T;
+    const T* X = static_cast<const T*>(a.x) + (size_t)b * a.T * a.Cin;
+    const T* DY = static_cast<const T*>(a.dy) + (size_t)b * a.Tout * a.Cout;
+    __syncthreads();
+    for (int idx = tid; idx < TK * VPR; idx += kThreads) {
+      const int row = idx / VPR, vc = idx % VPR;
+      const int t = t0 + row, co = co0 + vc * V;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (t < t_out_hi && co < a.Cout) v = *reinterpret_cast<const u32x4*>(DY + (size_t)t * a.Cout + co);
+      *reinterpret_cast<u32x4*>(ldsD + row * PITCH + vc * 16) = v;
+    }
+    for (int idx = tid; idx < xrows * VPR; idx += kThreads) {
+      const int row = idx / VPR, vc = idx % VPR;
+      const int t = t0 - a.pad + row, ci = ci0 + vc * V;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (t >= 0 && t < t_in_hi && ci < a.Cin) {
+        v = *reinterpret_cast<const u32x4*>(X + (size_t)t * a.Cin + ci);
+        if (a.in_slope != 1.0f) v = lrelu_vec<T>(v, a.in_slope);
+      }
+      *reinterpret_cast<u32x4*>(ldsX + row * PITCH + vc * 16) = v;
+    }
+    __syncthreads();
+
+    if constexpr (sizeof(T) == 2) {
+      // transposing reads: within a 16-lane group, lane 4q+p addresses row q, columns 4p..4p+3 and
+      // lane i receives column i of the 4 rows.  Group g = lane>>4 covers columns 16*(g&1).. of the
+      // wave's 32, and the k half h = g>>1 (rows 8h..8h+7 of the 16-row step, two reads of 4 rows).
+      const int i16 = lane & 15, q = i16 >> 2, p = i16 & 3, g = lane >> 4;
+      const int colA = (wi * 32 + 16 * (g & 1) + 4 * p) * 2;
+      const int colB = (wj * 32 + 16 * (g & 1) + 4 * p) * 2;
+      const int rowk = 8 * (g >> 1) + q;
+#pragma unroll 2
+      for (int s = 0; s < TK / 16; ++s) {
+        union { s16x4 half[2]; bf16x8 v; } fa;
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+          auto pa = reinterpret_cast<__attribute__((address_space(3))) s16x4*>(
+              (__attribute__((address_space(3))) unsigned char*)ldsD + (16 * s + rowk + 4 * rd) * PITCH + colA);
+          fa.half[rd] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(pa);
+        }
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+          union { s16x4 half[2]; bf16x8 v; } fb;
+#pragma unroll
+          for (int rd = 0; rd < 2; ++rd) {
+            auto pb = reinterpret_cast<__attribute__((address_space(3))) s16x4*>(
+                (__attribute__((address_space(3))) unsigned char*)ldsX + (16 * s + rowk + 4 * rd + k * a.dil) * PITCH + colB);
+            fb.half[rd] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(pb);
+          }
+          acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, fb.v, acc[k], 0, 0, 0);
+        }
+      }
+    } else {
+      const float* dA = reinterpret_cast<const float*>(ldsD) + wi * 32 + r;
+      const float* xB = reinterpret_cast<const float*>(ldsX) + wj * 32 + r;
+      constexpr int PF = PITCH / 4;
+#pragma unroll 4
+      for (int s = 0; s < TK / 2; ++s) {
+        const float av = dA[(2 * s + h) * PF];
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+          const float bv = xB[(2 * s + h + k * a.dil) * PF];
+          acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[k], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // slab of this split: partial[split][tap][co][ci]
+  float* P = a.partial + (size_t)blockIdx.x * KT * a.Cout * a.Cin;
+  const int ci = ci0 + wj * 32 + r;
+  if (ci < a.Cin) {
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int co = co0 + wi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (co < a.Cout) P[((size_t)k * a.Cout + co) * a.Cin + ci] = acc[k][i];
+      }
+  }
+}
+
+__global__ void reduce_slabs(const float* __restrict__ partial, float* __restrict__ dw, size_t n, int S, int accumulate) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = accumulate ? dw[i] : 0.f;
+  for (int k = 0; k < S; ++k) s += partial[(size_t)k * n + i];
+  dw[i] = s;
+}
+
+int pick_splits(int b, int t_out, int c_in, int c_out) {
+  const int tiles = vits::ceil_div(c_out, CT) * vits::ceil_div(c_in, CT);
+  const int chunks = b * vits::ceil_div(t_out, TK);
+  int s = 768 / tiles;
+  if (s < 1) s = 1;
+  if (s > chunks) s = chunks;
+  return s;
+}
+
+template <typename T, int KT>
+int launch(const WgradArgs& a, hipStream_t s) {
+  constexpr int PITCH = Pitch<T>::value;
+  const size_t lds = (size_t)(TK + TK + (KT - 1) * a.dil) * PITCH;
+  if (lds > (size_t)vits::kLdsBytesMax) return VITS_E_UNSUPPORTED;
+  auto kern = wgrad_kernel<T, KT>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return vits::note_hip_error(e, "vits_conv1d_cl_wgrad/attr");
+  }
+  dim3 grid(a.S, vits::ceil_div(a.Cout, CT), vits::ceil_div(a.Cin, CT));
+  hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, s, a);
+  return vits::check_launch("vits_conv1d_cl_wgrad");
+}
+
+template <typename T>
+int dispatch_k(const WgradArgs& a, hipStream_t s) {
+  switch (a.K) {
+    case 1: return launch<T, 1>(a, s);
+    case 3: return launch<T, 3>(a, s);
+    case 5: return launch<T, 5>(a, s);
+    case 7: return launch<T, 7>(a, s);
+    case 11: return launch<T, 11>(a, s);
+    default: return VITS_E_UNSUPPORTED;
+  }
+}
+
+}  // namespace
+
+extern "C" size_t vits_conv1d_cl_wgrad_workspace(int b, int t_out, int c_in, int c_out, int k) {
+  return (size_t)pick_splits(b, t_out, c_in, c_out) * k * c_out * c_in * sizeof(float);
+}
+
+extern "C" int vits_conv1d_cl_wgrad(int dtype, const void* x, const void* dy, float* dw, void* workspace,
+                                    size_t workspace_bytes, const int32_t* lengths, int b, int t, int c_in, int c_out,
+                                    int k, int dil, int pad, float in_slope, int flags, void* stream) {
+  if (!x || !dy || !dw || !workspace || b <= 0 || t <= 0 || c_in <= 0 || c_out <= 0 || k <= 0 || dil <= 0 || pad < 0)
+    return VITS_E_BADARG;
+  const int t_out = t + 2 * pad - dil * (k - 1);
+  if (t_out <= 0) return VITS_E_BADARG;
+  if (((flags & (VITS_CONV_MASK_IN | VITS_CONV_MASK_OUT)) != 0) && !lengths) return VITS_E_BADARG;
+  if (workspace_bytes < vits_conv1d_cl_wgrad_workspace(b, t_out, c_in, c_out, k)) return VITS_E_BADARG;
+  WgradArgs a{x, dy, static_cast<float*>(workspace), lengths, b, t, t_out, c_in, c_out, k, dil, pad,
+              pick_splits(b, t_out, c_in, c_out), vits::ceil_div(t_out, TK), in_slope, flags};
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rc;
+  if (dtype == VITS_DT_BF16) {
+    if (c_in % 8 != 0 || c_out % 8 != 0) return VITS_E_UNSUPPORTED;
+    rc = dispatch_k<__bf16>(a, s);
+  } else if (dtype == VITS_DT_F32) {
+    if (c_in % 4 != 0 || c_out % 4 != 0) return VITS_E_UNSUPPORTED;
+    rc = dispatch_k<float>(a, s);
+  } else {
+    return VITS_E_UNSUPPORTED;
+  }
+  if (rc != VITS_OK) return rc;
+  const size_t n = (size_t)k * c_out * c_in;
+  hipLaunchKernelGGL(reduce_slabs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.partial, dw, n, a.S,
+                     (flags & VITS_CONV_ACCUM) ? 1 : 0);
+  return vits::check_launch("vits_conv1d_cl_wgrad/reduce");
+}

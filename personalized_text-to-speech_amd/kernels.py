@@ -122,3 +122,73 @@ def stft_magnitude(y, n_fft, hop, win, window):
     spec = torch.stft(yp, n_fft, hop_length=hop, win_length=win, window=window, center=False,
                       normalized=False, onesided=True, return_complex=True)
     return torch.sqrt(spec.real.pow(2) + spec.imag.pow(2) + 1e-6)
+
+
+# ================================================================================================
+# Channels-last HIP convolution (csrc/conv1d_cl.hip).  Raw launcher: tensors are [b, t, c]
+# contiguous, weights are tap-major [k, c_out, c_in] in the activation dtype.
+# ================================================================================================
+CONV_MASK_IN, CONV_MASK_OUT, CONV_TANH, CONV_ACCUM = 1, 2, 4, 8
+_DT = {torch.float32: 0, torch.bfloat16: 2}
+
+
+def conv1d_cl_raw(x, w, bias=None, bias_b=None, res=None, mg_src=None, out=None, lengths=None, dil=1, pad=0,
+                  in_slope=1.0, mg_slope=1.0, out_scale=1.0, flags=0):
+    _lib.require_cuda(x, w)
+    assert x.is_contiguous() and w.is_contiguous() and x.dtype == w.dtype and x.dim() == 3 and w.dim() == 3
+    b, t, c_in = x.shape
+    k, c_out, c_in_w = w.shape
+    assert c_in_w == c_in
+    t_out = t + 2 * pad - dil * (k - 1)
+    if out is None:
+        assert not (flags & CONV_ACCUM)
+        out = torch.empty((b, t_out, c_out), device=x.device, dtype=x.dtype)
+    for tns in (res, mg_src, out):
+        assert tns is None or (tns.is_contiguous() and tns.dtype == x.dtype and tuple(tns.shape) == (b, t_out, c_out))
+    for tns in (bias, bias_b):
+        assert tns is None or (tns.dtype == torch.float32 and tns.is_contiguous())
+    assert lengths is None or lengths.dtype == torch.int32
+    p = lambda v: None if v is None else v.data_ptr()
+    e0 = _lib.timer.start("vits_conv1d_cl")
+    rc = _lib.lib().vits_conv1d_cl(_DT[x.dtype], x.data_ptr(), w.data_ptr(), p(bias), p(bias_b), p(res), p(mg_src),
+                                   out.data_ptr(), p(lengths), b, t, c_in, c_out, k, dil, pad,
+                                   float(in_slope), float(mg_slope), float(out_scale), int(flags), _lib.stream_ptr())
+    _lib.timer.stop("vits_conv1d_cl", e0, 2.0 * b * t_out * c_out * c_in * k)       # units = FLOP
+    _lib.check(rc, "vits_conv1d_cl")
+    return out
+
+
+_workspace = {}
+
+
+def workspace(nbytes, device):
+    """Grow-only device scratch shared by the kernels that need one (stream-ordered reuse)."""
+    buf = _workspace.get(device)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _workspace[device] = buf
+    return buf
+
+
+def conv1d_cl_wgrad_raw(x, dy, k, lengths=None, dil=1, pad=0, in_slope=1.0, flags=0, out=None):
+    """dW [k, c_out, c_in] float32 of conv1d_cl_raw(x, w, ...) given dy [b, t_out, c_out]."""
+    _lib.require_cuda(x, dy)
+    assert x.is_contiguous() and dy.is_contiguous() and x.dtype == dy.dtype
+    b, t, c_in = x.shape
+    c_out = dy.shape[2]
+    t_out = t + 2 * pad - dil * (k - 1)
+    assert tuple(dy.shape) == (b, t_out, c_out)
+    if out is None:
+        assert not (flags & CONV_ACCUM)
+        out = torch.empty((k, c_out, c_in), device=x.device, dtype=torch.float32)
+    assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (k, c_out, c_in)
+    L = _lib.lib()
+    ws_bytes = L.vits_conv1d_cl_wgrad_workspace(b, t_out, c_in, c_out, k)
+    ws = workspace(ws_bytes, x.device)
+    e0 = _lib.timer.start("vits_conv1d_cl_wgrad")
+    rc = L.vits_conv1d_cl_wgrad(_DT[x.dtype], x.data_ptr(), dy.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                None if lengths is None else lengths.data_ptr(), b, t, c_in, c_out, k, dil, pad,
+                                float(in_slope), int(flags), _lib.stream_ptr())
+    _lib.timer.stop("vits_conv1d_cl_wgrad", e0, 2.0 * b * t_out * c_out * c_in * k)
+    _lib.check(rc, "vits_conv1d_cl_wgrad")
+    return out

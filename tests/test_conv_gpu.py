@@ -1,0 +1,134 @@
+"""GPU: vits_conv1d_cl (channels-last MFMA convolution) against torch's conv1d in fp32 on the same
+inputs.  f32 kernel: tolerance 1e-5 relative (exact-fp32 MFMA, different summation order only);
+bf16 kernel: inputs/weights rounded to bf16 first, reference computed in fp32 from the rounded
+values, tolerance 1e-2 relative (bf16 output rounding)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def ref_conv(x_cl, w_tap, bias, dil, pad, in_slope):
+    x = x_cl.float().transpose(1, 2)                       # [b, c, t]
+    if in_slope != 1.0:
+        x = F.leaky_relu(x, in_slope)
+    w = w_tap.float().permute(1, 2, 0).contiguous()       # [c_out, c_in, k]
+    return F.conv1d(x, w, bias, 1, pad, dil).transpose(1, 2)
+
+
+def rel(a, b):
+    return float((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-12))
+
+
+CASES = [  # b, t, c_in, c_out, k, dil
+    (2, 96, 32, 32, 3, 1), (2, 300, 64, 64, 7, 3), (1, 257, 128, 128, 11, 5), (3, 200, 192, 384, 5, 1),
+    (2, 32, 192, 512, 7, 1), (2, 130, 256, 256, 3, 5), (1, 1000, 32, 32, 11, 1), (2, 77, 96, 192, 1, 1),
+    (2, 64, 768, 192, 3, 1), (1, 50, 40, 72, 5, 2),
+]
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("case", CASES)
+def test_plain_conv(pkg, case, dtype, tol):
+    b, t, ci, co, k, dil = case
+    torch.manual_seed(hash(case) % 1000)
+    pad = (k - 1) * dil // 2
+    x = torch.randn(b, t, ci, device=DEV).to(dtype)
+    w = (torch.randn(k, co, ci, device=DEV) / (ci * k) ** 0.5).to(dtype)
+    bias = torch.randn(co, device=DEV)
+    y = pkg.kernels.conv1d_cl_raw(x, w, bias, dil=dil, pad=pad)
+    assert rel(y, ref_conv(x, w, bias, dil, pad, 1.0)) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1.5e-2)])
+def test_fused_prologue_epilogue(pkg, dtype, tol):
+    torch.manual_seed(3)
+    K = pkg.kernels
+    b, t, c, k, dil = 3, 210, 64, 7, 3
+    pad = (k - 1) * dil // 2
+    x = torch.randn(b, t, c, device=DEV).to(dtype)
+    w = (torch.randn(k, c, c, device=DEV) / (c * k) ** 0.5).to(dtype)
+    bias, bias_b = torch.randn(c, device=DEV), torch.randn(b, c, device=DEV)
+    res = torch.randn(b, t, c, device=DEV).to(dtype)
+    lens = torch.tensor([210, 150, 33], device=DEV, dtype=torch.int32)
+    mask = (torch.arange(t, device=DEV)[None, :] < lens[:, None]).float().unsqueeze(-1)
+    # lrelu prologue + masked input + bias + per-item bias + residual + scale + masked output
+    y = K.conv1d_cl_raw(x, w, bias, bias_b, res=res, lengths=lens, dil=dil, pad=pad, in_slope=0.1, out_scale=0.5,
+                        flags=K.CONV_MASK_IN | K.CONV_MASK_OUT)
+    want = (ref_conv((x.float() * mask).to(dtype), w, bias, dil, pad, 0.1) + bias_b[:, None, :] + res.float()) * 0.5 * mask
+    assert rel(y, want) < tol
+    # accumulate + tanh
+    y0 = torch.randn(b, t, c, device=DEV).to(dtype)
+    y1 = y0.clone()
+    K.conv1d_cl_raw(x, w, None, out=y1, dil=dil, pad=pad, flags=K.CONV_ACCUM | K.CONV_TANH)
+    assert rel(y1, torch.tanh(ref_conv(x, w, None, dil, pad, 1.0)) + y0.float()) < tol
+    # chain-rule multiplier of a fused leaky-relu (data-gradient form)
+    src = torch.randn(b, t, c, device=DEV).to(dtype)
+    y2 = K.conv1d_cl_raw(x, w, None, mg_src=src, dil=dil, pad=pad, mg_slope=0.1)
+    assert rel(y2, ref_conv(x, w, None, dil, pad, 1.0) * torch.where(src.float() > 0, 1.0, 0.1)) < tol
+
+
+def test_data_gradient_identity(pkg):
+    """dX of conv(x, w) == the same kernel on dY with tap-flipped, transposed weights and
+    pad' = dil*(k-1) - pad (include/vitsmi.h)."""
+    torch.manual_seed(5)
+    b, t, ci, co, k, dil = 2, 140, 64, 96, 5, 2
+    pad = (k - 1) * dil // 2
+    x = torch.randn(b, t, ci, device=DEV, requires_grad=True)
+    w = torch.randn(k, co, ci, device=DEV) / (ci * k) ** 0.5
+    y = ref_conv(x, w, None, dil, pad, 1.0)
+    dy = torch.randn_like(y)
+    (dx_ref,) = torch.autograd.grad(y, x, dy)
+    w_t = w.flip(0).transpose(1, 2).contiguous()               # [k][ci][co]
+    dx = pkg.kernels.conv1d_cl_raw(dy.contiguous(), w_t, None, dil=dil, pad=dil * (k - 1) - pad)
+    assert rel(dx, dx_ref) < 2e-5
+
+
+def test_rejects_unsupported(pkg):
+    x = torch.zeros(1, 8, 6, device=DEV)
+    w = torch.zeros(1, 4, 6, device=DEV)
+    with pytest.raises(pkg._lib.VitsKernelError, match="UNSUPPORTED"):
+        pkg.kernels.conv1d_cl_raw(x, w)                          # c_in % 4 != 0
+
+
+WG_CASES = [  # b, t, c_in, c_out, k, dil
+    (2, 96, 32, 32, 3, 1), (2, 300, 64, 64, 7, 3), (1, 257, 128, 128, 11, 5), (3, 200, 192, 384, 5, 1),
+    (4, 2048, 32, 32, 11, 1), (2, 77, 96, 192, 1, 1), (2, 64, 768, 192, 3, 1), (1, 50, 40, 72, 5, 2),
+]
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 5e-5), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("case", WG_CASES)
+def test_weight_gradient(pkg, case, dtype, tol):
+    b, t, ci, co, k, dil = case
+    torch.manual_seed(hash(case) % 1000)
+    pad = (k - 1) * dil // 2
+    x = torch.randn(b, t, ci, device=DEV).to(dtype)
+    dy = torch.randn(b, t, co, device=DEV).to(dtype)
+    lens = torch.randint(t // 2, t + 1, (b,), device=DEV, dtype=torch.int32)
+    mask = (torch.arange(t, device=DEV)[None, :] < lens[:, None]).float().unsqueeze(-1)
+    w = torch.zeros(k, co, ci, device=DEV, requires_grad=True)
+    K = pkg.kernels
+    # plain
+    y = ref_conv(x, w, None, dil, pad, 0.1)
+    (want,) = torch.autograd.grad(y, w, dy.float())
+    got = K.conv1d_cl_wgrad_raw(x, dy, k, dil=dil, pad=pad, in_slope=0.1)
+    assert rel(got, want) < tol
+    # masked input and output rows, accumulated onto an existing gradient
+    y = ref_conv((x.float() * mask).to(dtype), w, None, dil, pad, 1.0) * mask
+    (want,) = torch.autograd.grad(y, w, dy.float())
+    base = torch.randn(k, co, ci, device=DEV)
+    got = base.clone()
+    K.conv1d_cl_wgrad_raw(x, dy, k, lengths=lens, dil=dil, pad=pad, flags=K.CONV_MASK_IN | K.CONV_MASK_OUT | K.CONV_ACCUM, out=got)
+    assert rel(got - base, want) < tol * 2
+
+
+def test_weight_gradient_is_reproducible(pkg):
+    torch.manual_seed(1)
+    x = torch.randn(4, 1000, 64, device=DEV).bfloat16()
+    dy = torch.randn(4, 1000, 64, device=DEV).bfloat16()
+    a = pkg.kernels.conv1d_cl_wgrad_raw(x, dy, 7, dil=1, pad=3).clone()
+    b = pkg.kernels.conv1d_cl_wgrad_raw(x, dy, 7, dil=1, pad=3)
+    assert torch.equal(a, b)
