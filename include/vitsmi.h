@@ -94,6 +94,8 @@ int vits_mas_f32(const float* neg_cent, void* path, int path_dtype,
 #define VITS_CONV_MASK_OUT  2   /* rows t >= lengths[b] of y written as zero ((...) * x_mask after)     */
 #define VITS_CONV_TANH      4   /* y = tanh(.)                                                          */
 #define VITS_CONV_ACCUM     8   /* y += result                                                          */
+#define VITS_CONV_RES_AFTER 16  /* add `res` after scale and the mg_src multiplier instead of before:
+                                   y = scale*(conv + bias)*lrelu'(mg_src) + res  (skip path of a data gradient) */
 int vits_conv1d_cl(int dtype, const void* x, const void* w, const float* bias, const float* bias_b,
                    const void* res, const void* mg_src, void* y, const int32_t* lengths,
                    int b, int t, int c_in, int c_out, int k, int dil, int pad,
@@ -111,6 +113,24 @@ size_t vits_conv1d_cl_wgrad_workspace(int b, int t_out, int c_in, int c_out, int
 int vits_conv1d_cl_wgrad(int dtype, const void* x, const void* dy, float* dw, void* workspace,
                          size_t workspace_bytes, const int32_t* lengths, int b, int t, int c_in, int c_out,
                          int k, int dil, int pad, float in_slope, int flags, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Channels-last ConvTranspose1d = 1x1 matrix-core product + overlap-add.
+ *
+ * Replaces: models.py:277 `self.ups[i](x)` (weight-normed torch.nn.ConvTranspose1d(c_in, c_out, k,
+ *           u, padding=(k-u)//2), models.py:254-258) and its backward.
+ *   forward : p = vits_conv1d_cl(x, w1 [1][k*c_out][c_in])  with  w1[0][j*c_out+co][ci] = W[ci][co][j],
+ *             then vits_convt_fold_cl:  y[b][to][co] = bias[co] + sum_{j: (to+pad-j)%u==0} p[b][(to+pad-j)/u][j*c_out+co]
+ *             with t_out = (t_in-1)*u - 2*pad + k;
+ *   backward: vits_convt_unfold_cl: dp[b][ti][j*c_out+co] = dy[b][ti*u + j - pad][co] (0 outside),
+ *             then the 1x1 data / weight gradients through vits_conv1d_cl / vits_conv1d_cl_wgrad.
+ *   p [b][t_in][k*c_out], y/dy [b][t_out][c_out]; bias float32[c_out] or NULL;
+ *   dtype VITS_DT_BF16 (c_out % 8 == 0) or VITS_DT_F32 (c_out % 4 == 0).
+ * ------------------------------------------------------------------------------------------ */
+int vits_convt_fold_cl(int dtype, const void* p, const float* bias, void* y, int b, int t_in, int c_out, int k,
+                       int u, int pad, void* stream);
+int vits_convt_unfold_cl(int dtype, const void* dy, void* dp, int b, int t_in, int c_out, int k, int u, int pad,
+                         void* stream);
 
 #ifdef __cplusplus
 }

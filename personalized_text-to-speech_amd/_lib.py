@@ -23,6 +23,8 @@ SIGNATURES = {
     "vits_abi_version": (c_int, []),
     "vits_last_error": (ctypes.c_char_p, []),
     "vits_mas_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "vits_convt_fold_cl": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "vits_convt_unfold_cl": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "vits_conv1d_cl_wgrad_workspace": (c_size_t, [c_int] * 5),
     "vits_conv1d_cl_wgrad": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p] + [c_int] * 7 + [c_float, c_int, c_void_p]),
     "vits_conv1d_cl": (c_int, [c_int] + [c_void_p] * 8 + [c_int] * 7 + [c_float] * 3 + [c_int, c_void_p]),

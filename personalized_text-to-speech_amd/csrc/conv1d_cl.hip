@@ -22,7 +22,7 @@
 //
 // Fused epilogue (flags): + bias[co] + bias_b[b][co] (speaker conditioning) + residual, * scale,
 // * leaky-relu'(src) (chain rule of a fused input activation, for the data-gradient call),
-// row mask, tanh, accumulate into Y.
+// residual after the multiplier (skip connection of a data gradient), row mask, tanh, accumulate.
 #include "common.h"
 
 namespace {
@@ -169,9 +169,11 @@ __global__ __launch_bounds__(kThreads) void conv1d_cl_kernel(ConvArgs a) {
       if (t >= a.Tout) continue;
       const size_t o = (size_t)t * a.Cout + co;
       float v = acc[n][i] + bsum;
-      if (R) v += to_f(R[o]);
+      const bool res_after = (a.flags & VITS_CONV_RES_AFTER) != 0;
+      if (R && !res_after) v += to_f(R[o]);
       v *= a.out_scale;
       if (MG) v *= (to_f(MG[o]) > 0.f) ? 1.0f : a.mg_slope;
+      if (R && res_after) v += to_f(R[o]);
       if (a.flags & VITS_CONV_TANH) v = tanhf(v);
       if ((a.flags & VITS_CONV_MASK_OUT) && t >= len) v = 0.f;
       if (a.flags & VITS_CONV_ACCUM) v += to_f(Y[o]);

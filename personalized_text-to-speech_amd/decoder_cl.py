@@ -1,0 +1,218 @@
+"""HiFi-GAN decoder (reference models.Generator, models.py:244-289; modules.ResBlock1/2 :187-256) as
+ONE autograd node over the channels-last HIP kernels.
+
+Forward = 1 + 4*(1+1) + 72 + 1 launches for the reference config (conv_pre, per stage the
+upsampler's 1x1 product + fold, 2 convolutions per ResBlock1 unit, conv_post); every element-wise
+op of the reference graph is folded into a convolution's prologue/epilogue:
+
+    reference op (models.py / modules.py)            here
+    -----------------------------------------------  -------------------------------------------------
+    x + self.cond(g)                     :272-273    per-item bias `bias_b` of conv_pre
+    F.leaky_relu(x, 0.1) before ups / c1 / c2        `in_slope` prologue of the consuming convolution
+    xt + x  (ResBlock skip)              :220        `res` epilogue of c2
+    xs += resblock(x);  xs / num_kernels :279-284    c2 of the last unit writes (.)/3 into xs (ACCUM)
+    F.leaky_relu(x) ; conv_post ; tanh   :285-287    `in_slope=0.01` prologue + TANH epilogue
+
+Backward is written by hand with the same kernels: data gradients are the forward kernel on dY with
+tap-flipped transposed weights and the leaky-relu derivative as `mg_src` epilogue; weight gradients
+come from vits_conv1d_cl_wgrad (fp32, reproducible).
+"""
+import torch
+
+from . import _lib
+from . import kernels as K
+
+
+def convt_fold(p, bias, c_out, k, u, pad):
+    b, t_in, _ = p.shape
+    t_out = (t_in - 1) * u - 2 * pad + k
+    y = torch.empty((b, t_out, c_out), device=p.device, dtype=p.dtype)
+    rc = _lib.lib().vits_convt_fold_cl(K._DT[p.dtype], p.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(),
+                                       b, t_in, c_out, k, u, pad, _lib.stream_ptr())
+    _lib.check(rc, "vits_convt_fold_cl")
+    return y
+
+
+def convt_unfold(dy, t_in, k, u, pad):
+    b, t_out, c_out = dy.shape
+    dp = torch.empty((b, t_in, k * c_out), device=dy.device, dtype=dy.dtype)
+    rc = _lib.lib().vits_convt_unfold_cl(K._DT[dy.dtype], dy.data_ptr(), dp.data_ptr(), b, t_in, c_out, k, u, pad, _lib.stream_ptr())
+    _lib.check(rc, "vits_convt_unfold_cl")
+    return dp
+
+
+def flip_t(w):
+    """[k][co][ci] -> data-gradient weights [k][ci][co] with the taps reversed."""
+    return w.flip(0).transpose(1, 2).contiguous()
+
+
+class DecoderPlan:
+    """Static description of a Generator instance (shapes only; no tensors)."""
+
+    def __init__(self, gen):
+        self.resblock1 = gen.resblocks[0].__class__.__name__ == "ResBlock1"
+        self.num_kernels = gen.num_kernels
+        self.ups = [(m.in_channels, m.out_channels, m.kernel_size, m.stride, m.padding) for m in gen.ups]
+        self.res = []                      # per resblock: (channels, k, dilations)
+        for rb in gen.resblocks:
+            convs = rb.convs1 if self.resblock1 else rb.convs
+            self.res.append((convs[0].in_channels, convs[0].kernel_size, [c.dilation for c in convs]))
+        self.c_last = gen.conv_post.in_channels
+
+
+def prepared_weights(gen):
+    """Parameters -> kernel-layout fp32 tensors (autograd-connected):  conv [c_out,c_in,k] ->
+    [k][c_out][c_in];  conv-transpose [c_in,c_out,k] -> [1][k*c_out][c_in];  conv_post padded to 8
+    output channels (vector width of the kernels)."""
+    out = [gen.conv_pre.weight.permute(2, 0, 1).contiguous(), gen.conv_pre.bias]
+    for i, up in enumerate(gen.ups):                               # consumption order of DecoderFn.forward
+        w = up.weight                                             # weight-normed [c_in, c_out, k]
+        out += [w.permute(2, 1, 0).reshape(1, up.kernel_size * up.out_channels, up.in_channels).contiguous(), up.bias]
+        for rb in gen.resblocks[i * gen.num_kernels:(i + 1) * gen.num_kernels]:
+            pairs = zip(rb.convs1, rb.convs2) if hasattr(rb, "convs1") else [(c,) for c in rb.convs]
+            for group in pairs:
+                for c in group:
+                    out += [c.weight.permute(2, 0, 1).contiguous(), c.bias]
+    wp = gen.conv_post.weight                                      # [1, c, 7]
+    wp = torch.cat([wp, wp.new_zeros(7, wp.size(1), wp.size(2))], 0)
+    out.append(wp.permute(2, 0, 1).contiguous())
+    return out
+
+
+class DecoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, plan, dtype, z, cond, *wb):
+        """z [b, t, c] channels-last (any float dtype), cond float32 [b, c_up0] or None, wb from
+        prepared_weights().  Returns y [b, t*prod(u), 8] in `dtype` (channel 0 is the waveform)."""
+        C = K.conv1d_cl_raw
+        w = [t.detach().to(dtype) if t.dim() == 3 else t.detach().float() for t in wb]     # weights in compute dtype, biases fp32
+        it = iter(range(len(w)))
+        saved = []
+        z = z.detach().to(dtype).contiguous()
+        i_pre = (next(it), next(it))
+        h = C(z, w[i_pre[0]], w[i_pre[1]], bias_b=None if cond is None else cond.detach().float().contiguous(), pad=3)
+        saved.append(z)
+        idx = {"pre": i_pre, "ups": [], "res": []}
+        ri = 0
+        for (c_in, c_out, k, u, pad) in plan.ups:
+            iu = (next(it), next(it))
+            idx["ups"].append(iu)
+            p = C(h, w[iu[0]], None, in_slope=0.1)
+            x = convt_fold(p, w[iu[1]], c_out, k, u, pad)
+            saved.append(h)
+            xs = torch.empty_like(x)
+            for j in range(plan.num_kernels):
+                ch, rk, dils = plan.res[ri]
+                ri += 1
+                r = x
+                units = []
+                for l, d in enumerate(dils):
+                    last = l == len(dils) - 1
+                    if plan.resblock1:
+                        i1, i2 = (next(it), next(it)), (next(it), next(it))
+                        t1 = C(r, w[i1[0]], w[i1[1]], dil=d, pad=(rk * d - d) // 2, in_slope=0.1)
+                        if last:
+                            C(t1, w[i2[0]], w[i2[1]], res=r, out=xs, pad=(rk - 1) // 2, in_slope=0.1,
+                              out_scale=1.0 / plan.num_kernels, flags=K.CONV_ACCUM if j > 0 else 0)
+                            r_new = None
+                        else:
+                            r_new = C(t1, w[i2[0]], w[i2[1]], res=r, pad=(rk - 1) // 2, in_slope=0.1)
+                        units.append((i1, i2, d))
+                        saved += [r, t1]
+                    else:
+                        i1 = (next(it), next(it))
+                        if last:
+                            C(r, w[i1[0]], w[i1[1]], res=r, out=xs, dil=d, pad=(rk * d - d) // 2, in_slope=0.1,
+                              out_scale=1.0 / plan.num_kernels, flags=K.CONV_ACCUM if j > 0 else 0)
+                            r_new = None
+                        else:
+                            r_new = C(r, w[i1[0]], w[i1[1]], res=r, dil=d, pad=(rk * d - d) // 2, in_slope=0.1)
+                        units.append((i1, None, d))
+                        saved.append(r)
+                    r = r_new
+                idx["res"].append(units)
+            h = xs
+        i_post = next(it)
+        y = C(h, w[i_post], None, pad=3, in_slope=0.01, flags=K.CONV_TANH)
+        saved += [h, y]
+        ctx.plan, ctx.dtype, ctx.idx, ctx.i_post = plan, dtype, idx, i_post
+        ctx.has_cond = cond is not None
+        ctx.n_saved = len(saved)
+        ctx.save_for_backward(*saved, *w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        plan, dtype, idx = ctx.plan, ctx.dtype, ctx.idx
+        C, WG = K.conv1d_cl_raw, K.conv1d_cl_wgrad_raw
+        saved = list(ctx.saved_tensors[: ctx.n_saved])
+        w = list(ctx.saved_tensors[ctx.n_saved:])
+        grads = [None] * len(w)
+
+        def bias_grad(d):
+            return d.sum((0, 1), dtype=torch.float32)
+
+        y = saved.pop()
+        h = saved.pop()
+        dpre = (dy.to(torch.float32) * (1.0 - y.float() ** 2)).to(dtype).contiguous()      # tanh'
+        grads[ctx.i_post] = WG(h, dpre, 7, pad=3, in_slope=0.01)
+        dh = C(dpre, flip_t(w[ctx.i_post]), None, mg_src=h, pad=3, mg_slope=0.01)
+
+        ri = len(plan.res)
+        for s in reversed(range(len(plan.ups))):
+            c_in, c_out, k, u, pad = plan.ups[s]
+            dxs = dh * (1.0 / plan.num_kernels)
+            dx = torch.empty_like(dxs)
+            for j in reversed(range(plan.num_kernels)):
+                ri -= 1
+                ch, rk, dils = plan.res[ri]
+                units = idx["res"][ri]
+                dr = dxs
+                for l in reversed(range(len(dils))):
+                    i1, i2, d = units[l]
+                    first = l == 0
+                    if plan.resblock1:
+                        t1 = saved.pop()
+                        r_in = saved.pop()
+                        p2, p1 = (rk - 1) // 2, (rk * d - d) // 2
+                        grads[i2[0]] = WG(t1, dr, rk, pad=p2, in_slope=0.1)
+                        grads[i2[1]] = bias_grad(dr)
+                        dt1 = C(dr, flip_t(w[i2[0]]), None, mg_src=t1, pad=p2, mg_slope=0.1)
+                        grads[i1[0]] = WG(r_in, dt1, rk, dil=d, pad=p1, in_slope=0.1)
+                        grads[i1[1]] = bias_grad(dt1)
+                        if first:     # gradient wrt the stage input x: accumulated over the parallel resblocks
+                            _dgrad_res(dt1, w[i1[0]], r_in, dr, d, p1, out=dx, accum=j < plan.num_kernels - 1)
+                            dr = None
+                        else:
+                            dr = _dgrad_res(dt1, w[i1[0]], r_in, dr, d, p1)
+                    else:
+                        r_in = saved.pop()
+                        p1 = (rk * d - d) // 2
+                        grads[i1[0]] = WG(r_in, dr, rk, dil=d, pad=p1, in_slope=0.1)
+                        grads[i1[1]] = bias_grad(dr)
+                        if first:
+                            _dgrad_res(dr, w[i1[0]], r_in, dr, d, p1, out=dx, accum=j < plan.num_kernels - 1)
+                            dr = None
+                        else:
+                            dr = _dgrad_res(dr, w[i1[0]], r_in, dr, d, p1)
+            # upsampler: x = fold(conv1x1(lrelu(h_prev)))
+            h_prev = saved.pop()
+            iu = idx["ups"][s]
+            grads[iu[1]] = bias_grad(dx)
+            dp = convt_unfold(dx, h_prev.size(1), k, u, pad)
+            grads[iu[0]] = WG(h_prev, dp, 1, in_slope=0.1)
+            dh = C(dp, flip_t(w[iu[0]]), None, mg_src=h_prev, mg_slope=0.1)
+        z = saved.pop()
+        i_pre = idx["pre"]
+        grads[i_pre[0]] = WG(z, dh, 7, pad=3)
+        grads[i_pre[1]] = bias_grad(dh)
+        dz = C(dh, flip_t(w[i_pre[0]]), None, pad=3)
+        dcond = dh.sum(1, dtype=torch.float32) if ctx.has_cond else None
+        return (None, None, dz, dcond, *grads)
+
+
+def _dgrad_res(dy, w, x_in, skip, dil, pad, out=None, accum=False):
+    """d/dx of  conv(lrelu_0.1(x)) + x  given the output gradient:  conv^T(dy) * lrelu'(x) + skip,
+    one kernel (RES_AFTER adds the skip term after the activation-derivative multiplier)."""
+    return K.conv1d_cl_raw(dy, flip_t(w), None, res=skip, mg_src=x_in, out=out, dil=dil, pad=pad, mg_slope=0.1,
+                           flags=K.CONV_RES_AFTER | (K.CONV_ACCUM if accum else 0))

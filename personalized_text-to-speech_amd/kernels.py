@@ -18,8 +18,8 @@ from . import monotonic_align as _ma
 
 BACKENDS = {
     "maximum_path": "hip",
-    "conv1d": "rocm",
-    "conv_transpose1d": "rocm",
+    "decoder (Generator: conv_pre, ups, ResBlocks, conv_post; fwd+bwd)": "hip",
+    "conv1d (other modules)": "rocm",
     "weight_norm": "rocm",
     "wn_gate": "rocm",
     "layer_norm_c": "rocm",
@@ -128,7 +128,7 @@ def stft_magnitude(y, n_fft, hop, win, window):
 # Channels-last HIP convolution (csrc/conv1d_cl.hip).  Raw launcher: tensors are [b, t, c]
 # contiguous, weights are tap-major [k, c_out, c_in] in the activation dtype.
 # ================================================================================================
-CONV_MASK_IN, CONV_MASK_OUT, CONV_TANH, CONV_ACCUM = 1, 2, 4, 8
+CONV_MASK_IN, CONV_MASK_OUT, CONV_TANH, CONV_ACCUM, CONV_RES_AFTER = 1, 2, 4, 8, 16
 _DT = {torch.float32: 0, torch.bfloat16: 2}
 
 

@@ -201,20 +201,16 @@ class Generator(nn.Module):
             self.cond = Conv1d(gin_channels, upsample_initial_channel, 1)
 
     def forward(self, x, g=None):
-        x = self.conv_pre(x)
-        if g is not None:
-            x = x + self.cond(g)
-        for i in range(self.num_upsamples):
-            x = K.leaky_relu(x, modules.LRELU_SLOPE)
-            x = self.ups[i](x)
-            xs = None
-            for j in range(self.num_kernels):
-                r = self.resblocks[i * self.num_kernels + j](x)
-                xs = r if xs is None else xs + r
-            x = xs / self.num_kernels
-        x = K.leaky_relu(x, 0.01)                                  # models.py:285: F.leaky_relu default slope
-        x = self.conv_post(x)
-        return torch.tanh(x)
+        """x [b, c, t] (reference layout) -> waveform [b, 1, t * prod(upsample_rates)].  The whole
+        stack runs as one autograd node over the channels-last HIP kernels (decoder_cl.DecoderFn);
+        bf16 compute under autocast, exact fp32 otherwise."""
+        from . import decoder_cl
+        if getattr(self, "_plan", None) is None:
+            self._plan = decoder_cl.DecoderPlan(self)
+        dtype = torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
+        cond = self.cond(g).squeeze(-1).float() if g is not None else None           # [b, c_up0], models.py:272-273
+        y = decoder_cl.DecoderFn.apply(self._plan, dtype, x.transpose(1, 2), cond, *decoder_cl.prepared_weights(self))
+        return y[..., 0].unsqueeze(1).float()
 
     def remove_weight_norm(self):
         raise NotImplementedError("weight-norm folding for inference is SURVEY §8 (f-2), not built yet")

@@ -1,0 +1,93 @@
+"""TEST-ONLY torch emulation of the channels-last HIP kernels' semantics (include/vitsmi.h), so the
+Python orchestration around them (decoder_cl, ...) can be checked on a machine without a GPU.
+Never used by the product."""
+import torch
+import torch.nn.functional as F
+
+
+def conv1d_cl_raw(x, w, bias=None, bias_b=None, res=None, mg_src=None, out=None, lengths=None, dil=1, pad=0,
+                  in_slope=1.0, mg_slope=1.0, out_scale=1.0, flags=0):
+    b, t, c_in = x.shape
+    k, c_out, c_in_w = w.shape
+    assert c_in_w == c_in, (tuple(x.shape), tuple(w.shape))
+    xf = x.float()
+    if flags & 1:
+        xf = xf * (torch.arange(t, device=x.device)[None, :, None] < lengths[:, None, None])
+    if in_slope != 1.0:
+        xf = F.leaky_relu(xf, in_slope)
+    v = F.conv1d(xf.transpose(1, 2), w.float().permute(1, 2, 0), None, 1, pad, dil).transpose(1, 2)
+    if bias is not None:
+        v = v + bias
+    if bias_b is not None:
+        v = v + bias_b[:, None, :]
+    after = bool(flags & 16)
+    if res is not None and not after:
+        v = v + res.float()
+    v = v * out_scale
+    if mg_src is not None:
+        v = v * torch.where(mg_src.float() > 0, 1.0, mg_slope)
+    if res is not None and after:
+        v = v + res.float()
+    if flags & 4:
+        v = torch.tanh(v)
+    if flags & 2:
+        v = v * (torch.arange(v.size(1), device=x.device)[None, :, None] < lengths[:, None, None])
+    if flags & 8:
+        v = v + out.float()
+    v = v.to(x.dtype)
+    if out is not None:
+        out.copy_(v)
+        return out
+    return v
+
+
+def conv1d_cl_wgrad_raw(x, dy, k, lengths=None, dil=1, pad=0, in_slope=1.0, flags=0, out=None):
+    b, t, c_in = x.shape
+    c_out = dy.shape[2]
+    w = torch.zeros(k, c_out, c_in, device=x.device, requires_grad=True)
+    xf, dyf = x.float(), dy.float()
+    if flags & 1:
+        xf = xf * (torch.arange(t, device=x.device)[None, :, None] < lengths[:, None, None])
+    if flags & 2:
+        dyf = dyf * (torch.arange(dy.size(1), device=x.device)[None, :, None] < lengths[:, None, None])
+    if in_slope != 1.0:
+        xf = F.leaky_relu(xf, in_slope)
+    with torch.enable_grad():
+        y = F.conv1d(xf.transpose(1, 2), w.permute(1, 2, 0), None, 1, pad, dil).transpose(1, 2)
+        (g,) = torch.autograd.grad(y, w, dyf)
+    if out is not None:
+        if flags & 8:
+            out.add_(g)
+        else:
+            out.copy_(g)
+        return out
+    return g
+
+
+def convt_fold(p, bias, c_out, k, u, pad):
+    b, t_in, _ = p.shape
+    t_out = (t_in - 1) * u - 2 * pad + k
+    y = torch.zeros(b, t_out + 2 * pad + k, c_out, device=p.device)
+    pf = p.float().view(b, t_in, k, c_out)
+    for j in range(k):
+        y[:, j:j + t_in * u:u][:, :t_in] += pf[:, :, j]
+    y = y[:, pad:pad + t_out]
+    if bias is not None:
+        y = y + bias
+    return y.to(p.dtype).contiguous()
+
+
+def convt_unfold(dy, t_in, k, u, pad):
+    b, t_out, c_out = dy.shape
+    dyp = F.pad(dy.float(), (0, 0, pad, pad + k + u))
+    cols = [dyp[:, j:j + t_in * u:u][:, :t_in] for j in range(k)]
+    return torch.stack(cols, 2).reshape(b, t_in, k * c_out).to(dy.dtype).contiguous()
+
+
+def install(pkg):
+    from importlib import import_module
+    dcl = import_module("personalized_text-to-speech_amd.decoder_cl")
+    pkg.kernels.conv1d_cl_raw = conv1d_cl_raw
+    pkg.kernels.conv1d_cl_wgrad_raw = conv1d_cl_wgrad_raw
+    dcl.convt_fold = convt_fold
+    dcl.convt_unfold = convt_unfold

@@ -1,0 +1,42 @@
+"""CPU: the hand-written forward/backward ORCHESTRATION of decoder_cl.DecoderFn, with the HIP
+kernels replaced by tests/cl_emul.py (a torch emulation of the C-ABI semantics): the composition
+of fused prologues/epilogues, data gradients and weight gradients must equal the oracle's
+autograd through models.Generator.  (The kernels themselves are checked on the GPU box.)"""
+import importlib
+
+import pytest
+import torch
+
+import cl_emul
+from model_util import build_tiny, load_tiny, rel_err
+from oracle import vits_torch as O
+
+
+@pytest.fixture()
+def emulated(pkg, monkeypatch):
+    dcl = importlib.import_module("personalized_text-to-speech_amd.decoder_cl")
+    monkeypatch.setattr(pkg.kernels, "conv1d_cl_raw", cl_emul.conv1d_cl_raw)
+    monkeypatch.setattr(pkg.kernels, "conv1d_cl_wgrad_raw", cl_emul.conv1d_cl_wgrad_raw)
+    monkeypatch.setattr(dcl, "convt_fold", cl_emul.convt_fold)
+    monkeypatch.setattr(dcl, "convt_unfold", cl_emul.convt_unfold)
+    return pkg
+
+
+def test_decoder_forward_backward_equals_oracle(emulated):
+    pkg = emulated
+    g_, cfg = load_tiny()
+    net = build_tiny(pkg, g_, cfg)
+    torch.manual_seed(0)
+    z, g = torch.randn(2, 16, 13), torch.randn(2, 8, 1)
+    dec = net.dec
+    sd = {("dec." + k): v.detach().clone().requires_grad_(True) for k, v in dec.state_dict().items()}
+    z_o, g_o = z.clone().requires_grad_(True), g.clone().requires_grad_(True)
+    y_o = O.generator(sd, cfg["model"], z_o, g_o)
+    probe = torch.randn_like(y_o)
+    (y_o * probe).sum().backward()
+    z_p, g_p = z.clone().requires_grad_(True), g.clone().requires_grad_(True)
+    y_p = dec(z_p, g_p)
+    (y_p * probe).sum().backward()
+    assert rel_err(y_p, y_o) < 1e-5 and rel_err(z_p.grad, z_o.grad) < 1e-5 and rel_err(g_p.grad, g_o.grad) < 1e-5
+    for k, p in dec.named_parameters():
+        assert rel_err(p.grad, sd["dec." + k].grad) < 2e-5, k
