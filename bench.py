@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--fp32", action="store_true", help="parity mode: no bf16 autocast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying the captured hipGraph")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -104,9 +105,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    use_graph = (world == 1) and not args.eager
+    if use_graph:
+        tuner.capture(batch, warmup=3)
+        step = tuner.replay
+    else:
+        step = lambda: tuner.step(batch)
     trace = os.environ.get("VITS_BENCH_TRACE") == "1"      # debugging aid: sync + log every step
     for i in range(args.warmup):
-        out = tuner.step(batch)
+        out = step()
         if trace:
             torch.cuda.synchronize()
             bad = [n for n, q in list(tuner.net_g.named_parameters()) + list(tuner.net_d.named_parameters()) if not torch.isfinite(q).all()]
@@ -116,7 +123,7 @@ def main():
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        out = tuner.step(batch)
+        out = step()
         if trace:
             torch.cuda.synchronize(); print(f"step {i} ok", file=sys.stderr, flush=True)
     sync()
@@ -150,7 +157,8 @@ def main():
                     data="synthetic",
                     config=dict(workload=f"{args.workload}: {cfg_name}.json, per-rank batch {batch_size}, T_y<= {T_y} frames, "
                                          f"T_x<= {T_x} tokens, segment {hps.train.segment_size} samples, fwd+bwd+AdamW (G and D)",
-                                parallelism=f"dp{world}", kernels=P.kernels.BACKENDS, losses=losses),
+                                parallelism=f"dp{world}", execution="hipGraph replay" if use_graph else "eager launches",
+                                kernels=P.kernels.BACKENDS, losses=losses),
                     roofline=roof)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(hps, cfgs)

@@ -166,20 +166,31 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
   }
 }
 
-__global__ void reduce_slabs(const float* __restrict__ partial, float* __restrict__ dw, size_t n, int S, int accumulate) {
+// dw[i] (+)= sum_s partial[s][i], fixed summation order.  One thread per 4 consecutive elements.
+__global__ void reduce_slabs(const float* __restrict__ partial, float* __restrict__ dw, size_t n4, size_t n, int S, int accumulate) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = accumulate ? dw[i] : 0.f;
-  for (int k = 0; k < S; ++k) s += partial[(size_t)k * n + i];
-  dw[i] = s;
+  if (i >= n4) return;
+  float4 acc = accumulate ? reinterpret_cast<const float4*>(dw)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = 0; k < S; ++k) {
+    const float4 v = reinterpret_cast<const float4*>(partial + (size_t)k * n)[i];
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  reinterpret_cast<float4*>(dw)[i] = acc;
 }
 
-int pick_splits(int b, int t_out, int c_in, int c_out) {
+// Number of (b,t)-reduction splits: enough workgroups to fill the chip, but never more slab traffic
+// than ~4x the reads of x and dy themselves (each split writes and re-reads one full dW).
+int pick_splits(int b, int t_out, int c_in, int c_out, int k) {
   const int tiles = vits::ceil_div(c_out, CT) * vits::ceil_div(c_in, CT);
   const int chunks = b * vits::ceil_div(t_out, TK);
-  int s = 768 / tiles;
-  if (s < 1) s = 1;
+  int s = 512 / tiles;
+  const double io_elems = (double)b * t_out * (c_in + c_out);
+  const double dw_elems = (double)k * c_out * c_in;
+  const int s_traffic = (int)(io_elems / (2.0 * dw_elems)) + 1;       // fp32 slab = 2x a bf16 element
+  if (s > s_traffic) s = s_traffic;
+  if (s > 64) s = 64;
   if (s > chunks) s = chunks;
+  if (s < 1) s = 1;
   return s;
 }
 
@@ -213,7 +224,7 @@ int dispatch_k(const WgradArgs& a, hipStream_t s) {
 }  // namespace
 
 extern "C" size_t vits_conv1d_cl_wgrad_workspace(int b, int t_out, int c_in, int c_out, int k) {
-  return (size_t)pick_splits(b, t_out, c_in, c_out) * k * c_out * c_in * sizeof(float);
+  return (size_t)pick_splits(b, t_out, c_in, c_out, k) * k * c_out * c_in * sizeof(float);
 }
 
 extern "C" int vits_conv1d_cl_wgrad(int dtype, const void* x, const void* dy, float* dw, void* workspace,
@@ -226,7 +237,7 @@ extern "C" int vits_conv1d_cl_wgrad(int dtype, const void* x, const void* dy, fl
   if (((flags & (VITS_CONV_MASK_IN | VITS_CONV_MASK_OUT)) != 0) && !lengths) return VITS_E_BADARG;
   if (workspace_bytes < vits_conv1d_cl_wgrad_workspace(b, t_out, c_in, c_out, k)) return VITS_E_BADARG;
   WgradArgs a{x, dy, static_cast<float*>(workspace), lengths, b, t, t_out, c_in, c_out, k, dil, pad,
-              pick_splits(b, t_out, c_in, c_out), vits::ceil_div(t_out, TK), in_slope, flags};
+              pick_splits(b, t_out, c_in, c_out, k), vits::ceil_div(t_out, TK), in_slope, flags};
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc;
   if (dtype == VITS_DT_BF16) {
@@ -239,8 +250,8 @@ extern "C" int vits_conv1d_cl_wgrad(int dtype, const void* x, const void* dy, fl
     return VITS_E_UNSUPPORTED;
   }
   if (rc != VITS_OK) return rc;
-  const size_t n = (size_t)k * c_out * c_in;
-  hipLaunchKernelGGL(reduce_slabs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.partial, dw, n, a.S,
+  const size_t n = (size_t)k * c_out * c_in;          // multiple of 16 (c_in % 4 == 0 and c_out % 4 == 0)
+  hipLaunchKernelGGL(reduce_slabs, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, a.partial, dw, n / 4, n, a.S,
                      (flags & VITS_CONV_ACCUM) ? 1 : 0);
   return vits::check_launch("vits_conv1d_cl_wgrad/reduce");
 }

@@ -35,10 +35,10 @@ class FineTuner:
         broadcast_parameters(self.net_g)
         broadcast_parameters(self.net_d)
         fused = self.device.type == "cuda"
-        self.optim_g = torch.optim.AdamW(self.net_g.parameters(), hps.train.learning_rate, betas=hps.train.betas,
-                                         eps=hps.train.eps, fused=fused)
-        self.optim_d = torch.optim.AdamW(self.net_d.parameters(), hps.train.learning_rate, betas=hps.train.betas,
-                                         eps=hps.train.eps, fused=fused)
+        kw = dict(betas=hps.train.betas, eps=hps.train.eps, fused=fused, capturable=fused)
+        self.optim_g = torch.optim.AdamW(self.net_g.parameters(), hps.train.learning_rate, **kw)
+        self.optim_d = torch.optim.AdamW(self.net_d.parameters(), hps.train.learning_rate, **kw)
+        self._graph = None
         self.buckets_g = GradBuckets(self.net_g.parameters(), bucket_bytes)
         self.buckets_d = GradBuckets(self.net_d.parameters(), bucket_bytes)
         self.sched_g = torch.optim.lr_scheduler.ExponentialLR(self.optim_g, gamma=hps.train.lr_decay)
@@ -104,6 +104,40 @@ class FineTuner:
         return dict(loss_disc=loss_disc.detach(), loss_gen=loss_gen.detach(), loss_fm=loss_fm.detach(),
                     loss_mel=loss_mel.detach(), loss_dur=loss_dur.detach(), loss_kl=loss_kl.detach(),
                     grad_norm_d=grad_norm_d, grad_norm_g=grad_norm_g)
+
+    # ---------------------------------------------------------------------------------------------
+    # hipGraph execution of the step (single GPU): the step is thousands of small kernels and is
+    # CPU-launch-bound in eager mode; once shapes are fixed (one length bucket) the whole iteration —
+    # both forwards, both backwards, both AdamW updates — is captured once and replayed.
+    # ---------------------------------------------------------------------------------------------
+    def capture(self, batch, warmup=3):
+        """Warm up (MIOpen solver selection, workspace growth, optimizer state) on a side stream,
+        then capture one step on `batch`'s storage.  Afterwards `replay()` runs one iteration on
+        whatever has been copied into those tensors."""
+        from . import _lib
+        assert self.device.type == "cuda" and self._graph is None
+        timer_was, _lib.timer.enabled = _lib.timer.enabled, False
+        self._static_batch = batch
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.step(batch)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._static_out = self.step(batch)
+        _lib.timer.enabled = timer_was
+        return self._static_out
+
+    def load_batch(self, batch):
+        for dst, src in zip(self._static_batch, batch):
+            dst.copy_(src, non_blocking=True)
+
+    def replay(self):
+        self._graph.replay()
+        return self._static_out
 
     def epoch_end(self):
         self.sched_g.step()            # ExponentialLR per epoch, finetune_speaker_v2.py:157-158
