@@ -85,6 +85,8 @@ int vits_mas_f32(const float* neg_cent, void* path, int path_dtype,
  *   mg_src [b][t_out][c_out] or NULL: multiply the result by lrelu'_{mg_slope}(mg_src) — the chain
  *          rule of a fused input activation when this call computes a data gradient;
  *   lengths int32[b] (valid rows per item) — needed by VITS_CONV_MASK_IN / _MASK_OUT;
+ *   The arguments travel in a vits_conv_desc (below); x and y may be channel slices of wider
+ *   tensors (row pitches ldx / ldy) and the convolution may be strided in time (discriminators).
  *   in_slope = 1 disables the input activation.  dtype: VITS_DT_BF16 (c_in % 8 == 0, fp32
  *   accumulate) or VITS_DT_F32 (c_in % 4 == 0; exact fp32 fmaf chain on the matrix core).
  * The data gradient of a convolution is the same call on dY with w' [k][c_in][c_out],
@@ -96,10 +98,30 @@ int vits_mas_f32(const float* neg_cent, void* path, int path_dtype,
 #define VITS_CONV_ACCUM     8   /* y += result                                                          */
 #define VITS_CONV_RES_AFTER 16  /* add `res` after scale and the mg_src multiplier instead of before:
                                    y = scale*(conv + bias)*lrelu'(mg_src) + res  (skip path of a data gradient) */
-int vits_conv1d_cl(int dtype, const void* x, const void* w, const float* bias, const float* bias_b,
-                   const void* res, const void* mg_src, void* y, const int32_t* lengths,
-                   int b, int t, int c_in, int c_out, int k, int dil, int pad,
-                   float in_slope, float mg_slope, float out_scale, int flags, void* stream);
+#define VITS_CONV_GATE      32  /* WaveNet gate (commons.py:103-110 fused_add_tanh_sigmoid_multiply): c_out = 2*gate_h,
+                                   y[b,t,c] = tanh(v[c]) * sigmoid(v[c + gate_h]) for c < gate_h, v = conv + bias + bias_b;
+                                   y has gate_h columns; y2 (optional, 2*gate_h columns) receives v for the backward */
+#define VITS_CONV_GATE_BWD  64  /* chain rule of that gate: c_out = gate_h, v = conv(+res)*scale is d(acts); with
+                                   (a, b) = mg_src[.., c], mg_src[.., c + gate_h] (the saved v of the forward):
+                                   y[.., c] = v * sigmoid(b) * (1 - tanh(a)^2),  y[.., c + gate_h] = v * tanh(a) * sigmoid(b) * (1 - sigmoid(b));
+                                   y and mg_src have 2*gate_h columns */
+
+/* All sizes in elements.  Zero in ldx / ldy / ldy2 / stride means "dense" / 1. */
+typedef struct vits_conv_desc {
+  int32_t dtype;            /* VITS_DT_BF16 | VITS_DT_F32 (x, w, y, y2, res, mg_src share it)           */
+  int32_t b, t, c_in, c_out, k, dil, pad;
+  int32_t stride;           /* time stride: t_out = (t + 2*pad - dil*(k-1) - 1) / stride + 1             */
+  int32_t flags;            /* VITS_CONV_*                                                                */
+  int32_t ldx;              /* row pitch of x   (>= c_in: x may be a channel slice of a wider tensor)    */
+  int32_t ldy;              /* row pitch of y, res and mg_src                                             */
+  int32_t ldy2;             /* row pitch of y2                                                            */
+  int32_t gate_h;           /* H of the gate flags                                                        */
+  float in_slope, mg_slope, out_scale, reserved;
+  const void* x;  const void* w;  const float* bias;  const float* bias_b;
+  const void* res;  const void* mg_src;  void* y;  void* y2;  const int32_t* lengths;
+} vits_conv_desc;
+
+int vits_conv1d_cl(const vits_conv_desc* desc, void* stream);
 
 /* Weight gradient of vits_conv1d_cl (same x, lengths, in_slope, MASK flags as the forward call):
  *   dw[tap][co][ci] (+)= sum_{b,t} dy[b][t][co] * lrelu_{in_slope}(x[b][t + tap*dil - pad][ci])
@@ -109,10 +131,17 @@ int vits_conv1d_cl(int dtype, const void* x, const void* w, const float* bias, c
  *   slabs, summed in a fixed order: results are bitwise reproducible);
  *   flags: VITS_CONV_MASK_IN (x rows >= lengths[b] are zero), VITS_CONV_MASK_OUT (dy rows >=
  *   lengths[b] are zero), VITS_CONV_ACCUM (add to dw instead of overwriting). */
+typedef struct vits_wgrad_desc {
+  int32_t dtype;            /* dtype of x and dy                                                          */
+  int32_t b, t, c_in, c_out, k, dil, pad, stride, flags;
+  int32_t ldx, lddy;        /* row pitches of x and dy (0 = dense)                                        */
+  float in_slope, reserved;
+  const void* x;  const void* dy;  float* dw;  void* workspace;  size_t workspace_bytes;
+  const int32_t* lengths;
+} vits_wgrad_desc;
+
 size_t vits_conv1d_cl_wgrad_workspace(int b, int t_out, int c_in, int c_out, int k);
-int vits_conv1d_cl_wgrad(int dtype, const void* x, const void* dy, float* dw, void* workspace,
-                         size_t workspace_bytes, const int32_t* lengths, int b, int t, int c_in, int c_out,
-                         int k, int dil, int pad, float in_slope, int flags, void* stream);
+int vits_conv1d_cl_wgrad(const vits_wgrad_desc* desc, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Channels-last ConvTranspose1d = 1x1 matrix-core product + overlap-add.

@@ -10,7 +10,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvitsmi.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_int = ctypes.c_int
 c_void_p = ctypes.c_void_p
@@ -26,9 +26,26 @@ SIGNATURES = {
     "vits_convt_fold_cl": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "vits_convt_unfold_cl": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "vits_conv1d_cl_wgrad_workspace": (c_size_t, [c_int] * 5),
-    "vits_conv1d_cl_wgrad": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p] + [c_int] * 7 + [c_float, c_int, c_void_p]),
-    "vits_conv1d_cl": (c_int, [c_int] + [c_void_p] * 8 + [c_int] * 7 + [c_float] * 3 + [c_int, c_void_p]),
+    "vits_conv1d_cl_wgrad": (c_int, [c_void_p, c_void_p]),
+    "vits_conv1d_cl": (c_int, [c_void_p, c_void_p]),
 }
+
+class ConvDesc(ctypes.Structure):
+    """vits_conv_desc of include/vitsmi.h"""
+    _fields_ = [(n, ctypes.c_int32) for n in ("dtype", "b", "t", "c_in", "c_out", "k", "dil", "pad", "stride", "flags",
+                                              "ldx", "ldy", "ldy2", "gate_h")] + \
+               [(n, c_float) for n in ("in_slope", "mg_slope", "out_scale", "reserved")] + \
+               [(n, c_void_p) for n in ("x", "w", "bias", "bias_b", "res", "mg_src", "y", "y2", "lengths")]
+
+
+class WgradDesc(ctypes.Structure):
+    """vits_wgrad_desc of include/vitsmi.h"""
+    _fields_ = [(n, ctypes.c_int32) for n in ("dtype", "b", "t", "c_in", "c_out", "k", "dil", "pad", "stride", "flags",
+                                              "ldx", "lddy")] + \
+               [(n, c_float) for n in ("in_slope", "reserved")] + \
+               [("x", c_void_p), ("dy", c_void_p), ("dw", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_size_t),
+                ("lengths", c_void_p)]
+
 
 _lib = None
 

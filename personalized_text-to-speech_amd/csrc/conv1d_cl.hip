@@ -41,11 +41,8 @@ template <> struct Elem<__bf16> { static constexpr int VEC = 8; static constexpr
 template <> struct Elem<float> { static constexpr int VEC = 4; static constexpr int KC = 32; };
 
 struct ConvArgs {
-  const void* x; const void* w; const float* bias; const float* bias_b; const void* res;
-  const void* mg_src; void* y; const int* lengths;
-  int B, T, Tout, Cin, Cout, K, dil, pad, G;   // G = taps staged per group
-  float in_slope, mg_slope, out_scale;
-  int flags;
+  vits_conv_desc d;
+  int Tout, G;            // output rows; taps staged per group
 };
 
 __device__ __forceinline__ float to_f(float v) { return v; }
@@ -67,9 +64,12 @@ __device__ __forceinline__ u32x4 lrelu_vec(u32x4 raw, float slope) {
   return out.u;
 }
 
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
+
 template <typename T, int NT>
-__global__ __launch_bounds__(kThreads) void conv1d_cl_kernel(ConvArgs a) {
+__global__ __launch_bounds__(kThreads) void conv1d_cl_kernel(ConvArgs args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const vits_conv_desc& a = args.d;
   constexpr int V = Elem<T>::VEC;
   constexpr int KC = Elem<T>::KC;
   constexpr int TN = 32 * NT;
@@ -78,16 +78,20 @@ __global__ __launch_bounds__(kThreads) void conv1d_cl_kernel(ConvArgs a) {
   const int wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int t0 = blockIdx.x * TM;
-  const int co0 = blockIdx.y * TN;
   const int b = blockIdx.z;
-  const int xrows = TM + (a.K - 1) * a.dil;
+  const int Tout = args.Tout;
+  const bool gate = (a.flags & VITS_CONV_GATE) != 0;
+  // output-channel origin of this workgroup: in GATE mode the NT tiles are split in two halves
+  // (columns co0.. of the tanh half and co0 + gate_h.. of the sigmoid half).
+  const int co0 = blockIdx.y * (gate ? TN / 2 : TN);
+  const int xrows = (TM - 1) * a.stride + (a.k - 1) * a.dil + 1;
   unsigned char* ldsX = smem;
   unsigned char* ldsW = smem + (size_t)xrows * PITCH;
 
-  const T* X = static_cast<const T*>(a.x) + (size_t)b * a.T * a.Cin;
+  const T* X = static_cast<const T*>(a.x) + (size_t)b * a.t * a.ldx;
   const T* W = static_cast<const T*>(a.w);
-  const int len = (a.lengths != nullptr) ? a.lengths[b] : a.T;
-  const int t_in_hi = (a.flags & VITS_CONV_MASK_IN) ? (len < a.T ? len : a.T) : a.T;
+  const int len = (a.lengths != nullptr) ? a.lengths[b] : a.t;
+  const int t_in_hi = (a.flags & VITS_CONV_MASK_IN) ? (len < a.t ? len : a.t) : a.t;
 
   f32x16 acc[NT];
 #pragma unroll
@@ -95,39 +99,46 @@ __global__ __launch_bounds__(kThreads) void conv1d_cl_kernel(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
 
-  for (int ci0 = 0; ci0 < a.Cin; ci0 += KC) {
-    for (int tg = 0; tg < a.K; tg += a.G) {
+  for (int ci0 = 0; ci0 < a.c_in; ci0 += KC) {
+    for (int tg = 0; tg < a.k; tg += args.G) {
       __syncthreads();                       // previous compute finished with ldsW (and ldsX)
       if (tg == 0) {
-        // ---- stage X rows [t0 - pad, t0 - pad + xrows) x channels [ci0, ci0 + KC)
+        // ---- stage X rows [t0*stride - pad, ... + xrows) x channels [ci0, ci0 + KC)
         for (int idx = tid; idx < xrows * 8; idx += kThreads) {
           const int row = idx >> 3, ch = idx & 7;
-          const int t = t0 - a.pad + row;
+          const int t = t0 * a.stride - a.pad + row;
           const int ci = ci0 + ch * V;
           u32x4 v = {0u, 0u, 0u, 0u};
-          if (t >= 0 && t < t_in_hi && ci < a.Cin) {
-            v = *reinterpret_cast<const u32x4*>(X + (size_t)t * a.Cin + ci);
+          if (t >= 0 && t < t_in_hi && ci < a.c_in) {
+            v = *reinterpret_cast<const u32x4*>(X + (size_t)t * a.ldx + ci);
             if (a.in_slope != 1.0f) v = lrelu_vec<T>(v, a.in_slope);
           }
           *reinterpret_cast<u32x4*>(ldsX + row * PITCH + ch * 16) = v;
         }
       }
-      // ---- stage W[tg .. tg+G)[co0 .. co0+TN)[ci0 .. ci0+KC)
-      const int ntap = (a.K - tg < a.G) ? (a.K - tg) : a.G;
+      // ---- stage W[tg .. tg+G)[this workgroup's TN output channels][ci0 .. ci0+KC)
+      const int ntap = (a.k - tg < args.G) ? (a.k - tg) : args.G;
       for (int idx = tid; idx < ntap * TN * 8; idx += kThreads) {
         const int ch = idx & 7;
         const int col = (idx >> 3) % TN;
         const int tl = (idx >> 3) / TN;
-        const int co = co0 + col, ci = ci0 + ch * V;
+        int co = co0 + col;
+        bool ok = co < a.c_out;
+        if (gate) {
+          const int half = col / (TN / 2), sub = col % (TN / 2);
+          co = co0 + sub + half * a.gate_h;
+          ok = (co0 + sub) < a.gate_h;
+        }
+        const int ci = ci0 + ch * V;
         u32x4 v = {0u, 0u, 0u, 0u};
-        if (co < a.Cout && ci < a.Cin)
-          v = *reinterpret_cast<const u32x4*>(W + ((size_t)(tg + tl) * a.Cout + co) * a.Cin + ci);
+        if (ok && ci < a.c_in)
+          v = *reinterpret_cast<const u32x4*>(W + ((size_t)(tg + tl) * a.c_out + co) * a.c_in + ci);
         *reinterpret_cast<u32x4*>(ldsW + (tl * TN + col) * PITCH + ch * 16) = v;
       }
       __syncthreads();
       // ---- MFMA over the staged taps and the chunk's 4 macro-steps
       for (int tl = 0; tl < ntap; ++tl) {
-        const unsigned char* xa = ldsX + (wave * 32 + r + (tg + tl) * a.dil) * PITCH + 16 * h;
+        const unsigned char* xa = ldsX + ((wave * 32 + r) * a.stride + (tg + tl) * a.dil) * PITCH + 16 * h;
         const unsigned char* wb = ldsW + (tl * TN + r) * PITCH + 16 * h;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
@@ -153,25 +164,62 @@ __global__ __launch_bounds__(kThreads) void conv1d_cl_kernel(ConvArgs a) {
   }
 
   // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-  T* Y = static_cast<T*>(a.y) + (size_t)b * a.Tout * a.Cout;
-  const T* R = a.res ? static_cast<const T*>(a.res) + (size_t)b * a.Tout * a.Cout : nullptr;
-  const T* MG = a.mg_src ? static_cast<const T*>(a.mg_src) + (size_t)b * a.Tout * a.Cout : nullptr;
+  T* Y = static_cast<T*>(a.y) + (size_t)b * Tout * a.ldy;
+  const T* R = a.res ? static_cast<const T*>(a.res) + (size_t)b * Tout * a.ldy : nullptr;
+  const T* MG = a.mg_src ? static_cast<const T*>(a.mg_src) + (size_t)b * Tout * a.ldy : nullptr;
+
+  if (gate) {
+    // WaveNet gate (reference commons.py:103-110): tiles [0, NT/2) hold a = x_in[:, co], tiles [NT/2, NT) hold
+    // b = x_in[:, co + H];  y = tanh(a) * sigmoid(b);  optionally y2 keeps the pre-activations (for backward).
+    if constexpr (NT >= 2) {
+      T* Y2 = a.y2 ? static_cast<T*>(a.y2) + (size_t)b * Tout * a.ldy2 : nullptr;
+#pragma unroll
+      for (int n = 0; n < NT / 2; ++n) {
+        const int co = co0 + n * 32 + r;
+        if (co >= a.gate_h) continue;
+        float ba = 0.f, bb = 0.f;
+        if (a.bias) { ba += a.bias[co]; bb += a.bias[co + a.gate_h]; }
+        if (a.bias_b) { ba += a.bias_b[(size_t)b * a.c_out + co]; bb += a.bias_b[(size_t)b * a.c_out + co + a.gate_h]; }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int t = t0 + wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          if (t >= Tout) continue;
+          const float va = acc[n][i] + ba, vb = acc[n + NT / 2][i] + bb;
+          if (Y2) {
+            Y2[(size_t)t * a.ldy2 + co] = from_f<T>(va);
+            Y2[(size_t)t * a.ldy2 + co + a.gate_h] = from_f<T>(vb);
+          }
+          Y[(size_t)t * a.ldy + co] = from_f<T>(tanhf(va) * sigmoidf_(vb));
+        }
+      }
+    }
+    return;
+  }
+
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     const int co = co0 + n * 32 + r;
-    if (co >= a.Cout) continue;
+    if (co >= a.c_out) continue;
     float bsum = 0.f;
     if (a.bias) bsum += a.bias[co];
-    if (a.bias_b) bsum += a.bias_b[(size_t)b * a.Cout + co];
+    if (a.bias_b) bsum += a.bias_b[(size_t)b * a.c_out + co];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int t = t0 + wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-      if (t >= a.Tout) continue;
-      const size_t o = (size_t)t * a.Cout + co;
+      if (t >= Tout) continue;
+      const size_t o = (size_t)t * a.ldy + co;
       float v = acc[n][i] + bsum;
       const bool res_after = (a.flags & VITS_CONV_RES_AFTER) != 0;
       if (R && !res_after) v += to_f(R[o]);
       v *= a.out_scale;
+      if (a.flags & VITS_CONV_GATE_BWD) {
+        // chain rule of the gate: v = d(acts[:, co]);  mg_src = saved pre-activations [.., 2H]
+        const float ta = tanhf(to_f(MG[o])), sb = sigmoidf_(to_f(MG[o + a.gate_h]));
+        const bool dead = (a.flags & VITS_CONV_MASK_OUT) && t >= len;
+        Y[o] = from_f<T>(dead ? 0.f : v * sb * (1.0f - ta * ta));
+        Y[o + a.gate_h] = from_f<T>(dead ? 0.f : v * ta * sb * (1.0f - sb));
+        continue;
+      }
       if (MG) v *= (to_f(MG[o]) > 0.f) ? 1.0f : a.mg_slope;
       if (R && res_after) v += to_f(R[o]);
       if (a.flags & VITS_CONV_TANH) v = tanhf(v);
@@ -183,14 +231,13 @@ __global__ __launch_bounds__(kThreads) void conv1d_cl_kernel(ConvArgs a) {
 }
 
 template <typename T, int NT>
-int launch_conv(const ConvArgs& a, hipStream_t s) {
-  ConvArgs args = a;
+int launch_conv(const vits_conv_desc& d, int t_out, hipStream_t s) {
+  ConvArgs args{d, t_out, 1};
   const int TN = 32 * NT;
-  const int xrows = TM + (a.K - 1) * a.dil;
-  // taps per W stage: keep the W slab under ~40 KB
-  int G = (40 * 1024) / (TN * PITCH);
+  const int xrows = (TM - 1) * d.stride + (d.k - 1) * d.dil + 1;
+  int G = (40 * 1024) / (TN * PITCH);            // taps per W stage: keep the W slab under ~40 KB
   if (G < 1) G = 1;
-  if (G > a.K) G = a.K;
+  if (G > d.k) G = d.k;
   args.G = G;
   const size_t lds = (size_t)xrows * PITCH + (size_t)G * TN * PITCH;
   if (lds > (size_t)vits::kLdsBytesMax) return VITS_E_UNSUPPORTED;
@@ -199,39 +246,47 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return vits::note_hip_error(e, "vits_conv1d_cl/attr");
   }
-  dim3 grid(vits::ceil_div(a.Tout, TM), vits::ceil_div(a.Cout, TN), a.B);
+  const bool gate = (d.flags & VITS_CONV_GATE) != 0;
+  const int cols = gate ? d.gate_h : d.c_out;
+  dim3 grid(vits::ceil_div(t_out, TM), vits::ceil_div(cols, gate ? TN / 2 : TN), d.b);
   hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, s, args);
   return vits::check_launch("vits_conv1d_cl");
 }
 
 template <typename T>
-int dispatch_nt(const ConvArgs& a, hipStream_t s) {
-  if (a.Cout > 64) return launch_conv<T, 4>(a, s);
-  if (a.Cout > 32) return launch_conv<T, 2>(a, s);
-  return launch_conv<T, 1>(a, s);
+int dispatch_nt(const vits_conv_desc& d, int t_out, hipStream_t s) {
+  if (d.flags & VITS_CONV_GATE) return launch_conv<T, 4>(d, t_out, s);
+  if (d.c_out > 64) return launch_conv<T, 4>(d, t_out, s);
+  if (d.c_out > 32) return launch_conv<T, 2>(d, t_out, s);
+  return launch_conv<T, 1>(d, t_out, s);
 }
 
 }  // namespace
 
-extern "C" int vits_conv1d_cl(int dtype, const void* x, const void* w, const float* bias, const float* bias_b,
-                              const void* res, const void* mg_src, void* y, const int32_t* lengths,
-                              int b, int t, int c_in, int c_out, int k, int dil, int pad,
-                              float in_slope, float mg_slope, float out_scale, int flags, void* stream) {
-  if (!x || !w || !y || b <= 0 || t <= 0 || c_in <= 0 || c_out <= 0 || k <= 0 || dil <= 0 || pad < 0) return VITS_E_BADARG;
-  const int t_out = t + 2 * pad - dil * (k - 1);
-  if (t_out <= 0) return VITS_E_BADARG;
-  if (((flags & (VITS_CONV_MASK_IN | VITS_CONV_MASK_OUT)) != 0) && !lengths) return VITS_E_BADARG;
-  if ((res || mg_src) && t_out != t) return VITS_E_UNSUPPORTED;
-  ConvArgs a{x, w, bias, bias_b, res, mg_src, y, lengths, b, t, t_out, c_in, c_out, k, dil, pad, 1,
-             in_slope, mg_slope, out_scale, flags};
+extern "C" int vits_conv1d_cl(const vits_conv_desc* desc, void* stream) {
+  if (!desc) return VITS_E_BADARG;
+  vits_conv_desc d = *desc;
+  if (!d.x || !d.w || !d.y || d.b <= 0 || d.t <= 0 || d.c_in <= 0 || d.c_out <= 0 || d.k <= 0 || d.dil <= 0 || d.pad < 0)
+    return VITS_E_BADARG;
+  if (d.stride <= 0) d.stride = 1;
+  const int span = d.t + 2 * d.pad - d.dil * (d.k - 1) - 1;
+  if (span < 0) return VITS_E_BADARG;
+  const int t_out = span / d.stride + 1;
+  if (((d.flags & (VITS_CONV_MASK_IN | VITS_CONV_MASK_OUT)) != 0) && !d.lengths) return VITS_E_BADARG;
+  const bool gate = (d.flags & VITS_CONV_GATE) != 0, gate_bwd = (d.flags & VITS_CONV_GATE_BWD) != 0;
+  if (gate && (d.gate_h <= 0 || d.c_out != 2 * d.gate_h)) return VITS_E_BADARG;
+  if (gate_bwd && (d.gate_h != d.c_out || !d.mg_src)) return VITS_E_BADARG;
+  if (d.ldx <= 0) d.ldx = d.c_in;
+  if (d.ldy <= 0) d.ldy = gate ? d.gate_h : (gate_bwd ? 2 * d.gate_h : d.c_out);
+  if (d.ldy2 <= 0) d.ldy2 = d.c_out;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (dtype == VITS_DT_BF16) {
-    if (c_in % 8 != 0) return VITS_E_UNSUPPORTED;
-    return dispatch_nt<__bf16>(a, s);
+  if (d.dtype == VITS_DT_BF16) {
+    if (d.c_in % 8 != 0 || d.ldx % 8 != 0) return VITS_E_UNSUPPORTED;
+    return dispatch_nt<__bf16>(d, t_out, s);
   }
-  if (dtype == VITS_DT_F32) {
-    if (c_in % 4 != 0) return VITS_E_UNSUPPORTED;
-    return dispatch_nt<float>(a, s);
+  if (d.dtype == VITS_DT_F32) {
+    if (d.c_in % 4 != 0 || d.ldx % 4 != 0) return VITS_E_UNSUPPORTED;
+    return dispatch_nt<float>(d, t_out, s);
   }
   return VITS_E_UNSUPPORTED;
 }

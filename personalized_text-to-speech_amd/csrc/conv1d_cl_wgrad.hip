@@ -33,6 +33,7 @@ struct WgradArgs {
   int B, T, Tout, Cin, Cout, K, dil, pad, S, chunks_per_item;
   float in_slope;
   int flags;
+  int ldx, lddy, stride;
 };
 
 __device__ __forceinline__ float to_f(float v) { return v; }
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
   const int wi = wave >> 1, wj = wave & 1;
   const int r = lane & 31, h = lane >> 5;
   const int co0 = blockIdx.y * CT, ci0 = blockIdx.z * CT;
-  const int xrows = TK + (KT - 1) * a.dil;
+  const int xrows = (TK - 1) * a.stride + (KT - 1) * a.dil + 1;
   unsigned char* ldsD = smem;                               // [TK][CT] of dY
   unsigned char* ldsX = smem + (size_t)TK * PITCH;          // [xrows][CT] of act(X)
 
@@ -85,22 +86,22 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
     const int len = a.lengths ? a.lengths[b] : a.T;
     const int t_out_hi = (a.flags & VITS_CONV_MASK_OUT) ? (len < a.Tout ? len : a.Tout) : a.Tout;
     const int t_in_hi = (a.flags & VITS_CONV_MASK_IN) ? (len < a.T ? len : a.T) : a.T;
-    const T* X = static_cast<const T*>(a.x) + (size_t)b * a.T * a.Cin;
-    const T* DY = static_cast<const T*>(a.dy) + (size_t)b * a.Tout * a.Cout;
+    const T* X = static_cast<const T*>(a.x) + (size_t)b * a.T * a.ldx;
+    const T* DY = static_cast<const T*>(a.dy) + (size_t)b * a.Tout * a.lddy;
     __syncthreads();
     for (int idx = tid; idx < TK * VPR; idx += kThreads) {
       const int row = idx / VPR, vc = idx % VPR;
       const int t = t0 + row, co = co0 + vc * V;
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (t < t_out_hi && co < a.Cout) v = *reinterpret_cast<const u32x4*>(DY + (size_t)t * a.Cout + co);
+      if (t < t_out_hi && co < a.Cout) v = *reinterpret_cast<const u32x4*>(DY + (size_t)t * a.lddy + co);
       *reinterpret_cast<u32x4*>(ldsD + row * PITCH + vc * 16) = v;
     }
     for (int idx = tid; idx < xrows * VPR; idx += kThreads) {
       const int row = idx / VPR, vc = idx % VPR;
-      const int t = t0 - a.pad + row, ci = ci0 + vc * V;
+      const int t = t0 * a.stride - a.pad + row, ci = ci0 + vc * V;
       u32x4 v = {0u, 0u, 0u, 0u};
       if (t >= 0 && t < t_in_hi && ci < a.Cin) {
-        v = *reinterpret_cast<const u32x4*>(X + (size_t)t * a.Cin + ci);
+        v = *reinterpret_cast<const u32x4*>(X + (size_t)t * a.ldx + ci);
         if (a.in_slope != 1.0f) v = lrelu_vec<T>(v, a.in_slope);
       }
       *reinterpret_cast<u32x4*>(ldsX + row * PITCH + vc * 16) = v;
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
           for (int rd = 0; rd < 2; ++rd) {
             auto pb = reinterpret_cast<__attribute__((address_space(3))) s16x4*>(
-                (__attribute__((address_space(3))) unsigned char*)ldsX + (16 * s + rowk + 4 * rd + k * a.dil) * PITCH + colB);
+                (__attribute__((address_space(3))) unsigned char*)ldsX + ((16 * s + rowk + 4 * rd) * a.stride + k * a.dil) * PITCH + colB);
             fb.half[rd] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(pb);
           }
           acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, fb.v, acc[k], 0, 0, 0);
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
         const float av = dA[(2 * s + h) * PF];
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
-          const float bv = xB[(2 * s + h + k * a.dil) * PF];
+          const float bv = xB[((2 * s + h) * a.stride + k * a.dil) * PF];
           acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[k], 0, 0, 0);
         }
       }
@@ -197,7 +198,7 @@ int pick_splits(int b, int t_out, int c_in, int c_out, int k) {
 template <typename T, int KT>
 int launch(const WgradArgs& a, hipStream_t s) {
   constexpr int PITCH = Pitch<T>::value;
-  const size_t lds = (size_t)(TK + TK + (KT - 1) * a.dil) * PITCH;
+  const size_t lds = (size_t)(TK + (TK - 1) * a.stride + (KT - 1) * a.dil + 1) * PITCH;
   if (lds > (size_t)vits::kLdsBytesMax) return VITS_E_UNSUPPORTED;
   auto kern = wgrad_kernel<T, KT>;
   if (lds > 64 * 1024) {
@@ -227,31 +228,37 @@ extern "C" size_t vits_conv1d_cl_wgrad_workspace(int b, int t_out, int c_in, int
   return (size_t)pick_splits(b, t_out, c_in, c_out, k) * k * c_out * c_in * sizeof(float);
 }
 
-extern "C" int vits_conv1d_cl_wgrad(int dtype, const void* x, const void* dy, float* dw, void* workspace,
-                                    size_t workspace_bytes, const int32_t* lengths, int b, int t, int c_in, int c_out,
-                                    int k, int dil, int pad, float in_slope, int flags, void* stream) {
-  if (!x || !dy || !dw || !workspace || b <= 0 || t <= 0 || c_in <= 0 || c_out <= 0 || k <= 0 || dil <= 0 || pad < 0)
+extern "C" int vits_conv1d_cl_wgrad(const vits_wgrad_desc* desc, void* stream) {
+  if (!desc) return VITS_E_BADARG;
+  vits_wgrad_desc d = *desc;
+  if (!d.x || !d.dy || !d.dw || !d.workspace || d.b <= 0 || d.t <= 0 || d.c_in <= 0 || d.c_out <= 0 || d.k <= 0 ||
+      d.dil <= 0 || d.pad < 0)
     return VITS_E_BADARG;
-  const int t_out = t + 2 * pad - dil * (k - 1);
-  if (t_out <= 0) return VITS_E_BADARG;
-  if (((flags & (VITS_CONV_MASK_IN | VITS_CONV_MASK_OUT)) != 0) && !lengths) return VITS_E_BADARG;
-  if (workspace_bytes < vits_conv1d_cl_wgrad_workspace(b, t_out, c_in, c_out, k)) return VITS_E_BADARG;
-  WgradArgs a{x, dy, static_cast<float*>(workspace), lengths, b, t, t_out, c_in, c_out, k, dil, pad,
-              pick_splits(b, t_out, c_in, c_out, k), vits::ceil_div(t_out, TK), in_slope, flags};
+  if (d.stride <= 0) d.stride = 1;
+  const int span = d.t + 2 * d.pad - d.dil * (d.k - 1) - 1;
+  if (span < 0) return VITS_E_BADARG;
+  const int t_out = span / d.stride + 1;
+  if (((d.flags & (VITS_CONV_MASK_IN | VITS_CONV_MASK_OUT)) != 0) && !d.lengths) return VITS_E_BADARG;
+  if (d.workspace_bytes < vits_conv1d_cl_wgrad_workspace(d.b, t_out, d.c_in, d.c_out, d.k)) return VITS_E_BADARG;
+  if (d.ldx <= 0) d.ldx = d.c_in;
+  if (d.lddy <= 0) d.lddy = d.c_out;
+  WgradArgs a{d.x, d.dy, static_cast<float*>(d.workspace), d.lengths, d.b, d.t, t_out, d.c_in, d.c_out, d.k, d.dil, d.pad,
+              pick_splits(d.b, t_out, d.c_in, d.c_out, d.k), vits::ceil_div(t_out, TK), d.in_slope, d.flags,
+              d.ldx, d.lddy, d.stride};
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc;
-  if (dtype == VITS_DT_BF16) {
-    if (c_in % 8 != 0 || c_out % 8 != 0) return VITS_E_UNSUPPORTED;
+  if (d.dtype == VITS_DT_BF16) {
+    if (d.c_in % 8 != 0 || d.c_out % 8 != 0 || d.ldx % 8 != 0 || d.lddy % 8 != 0) return VITS_E_UNSUPPORTED;
     rc = dispatch_k<__bf16>(a, s);
-  } else if (dtype == VITS_DT_F32) {
-    if (c_in % 4 != 0 || c_out % 4 != 0) return VITS_E_UNSUPPORTED;
+  } else if (d.dtype == VITS_DT_F32) {
+    if (d.c_in % 4 != 0 || d.c_out % 4 != 0 || d.ldx % 4 != 0 || d.lddy % 4 != 0) return VITS_E_UNSUPPORTED;
     rc = dispatch_k<float>(a, s);
   } else {
     return VITS_E_UNSUPPORTED;
   }
   if (rc != VITS_OK) return rc;
-  const size_t n = (size_t)k * c_out * c_in;          // multiple of 16 (c_in % 4 == 0 and c_out % 4 == 0)
-  hipLaunchKernelGGL(reduce_slabs, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, a.partial, dw, n / 4, n, a.S,
-                     (flags & VITS_CONV_ACCUM) ? 1 : 0);
+  const size_t n = (size_t)d.k * d.c_out * d.c_in;          // multiple of 16 (c_in % 4 == 0 and c_out % 4 == 0)
+  hipLaunchKernelGGL(reduce_slabs, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, a.partial, d.dw, n / 4, n, a.S,
+                     (d.flags & VITS_CONV_ACCUM) ? 1 : 0);
   return vits::check_launch("vits_conv1d_cl_wgrad/reduce");
 }

@@ -128,31 +128,48 @@ def stft_magnitude(y, n_fft, hop, win, window):
 # Channels-last HIP convolution (csrc/conv1d_cl.hip).  Raw launcher: tensors are [b, t, c]
 # contiguous, weights are tap-major [k, c_out, c_in] in the activation dtype.
 # ================================================================================================
-CONV_MASK_IN, CONV_MASK_OUT, CONV_TANH, CONV_ACCUM, CONV_RES_AFTER = 1, 2, 4, 8, 16
+CONV_MASK_IN, CONV_MASK_OUT, CONV_TANH, CONV_ACCUM, CONV_RES_AFTER, CONV_GATE, CONV_GATE_BWD = 1, 2, 4, 8, 16, 32, 64
 _DT = {torch.float32: 0, torch.bfloat16: 2}
 
 
-def conv1d_cl_raw(x, w, bias=None, bias_b=None, res=None, mg_src=None, out=None, lengths=None, dil=1, pad=0,
-                  in_slope=1.0, mg_slope=1.0, out_scale=1.0, flags=0):
+def _rows(t, name):
+    """A [b, t, c] tensor whose rows are dense in c and whose batches follow each other: returns its
+    row pitch.  Covers contiguous tensors and channel slices x[..., a:b] of contiguous tensors."""
+    assert t.dim() == 3 and t.stride(2) == 1 and (t.size(0) == 1 or t.stride(0) == t.size(1) * t.stride(1)), \
+        f"{name}: unsupported strides {t.stride()} for shape {tuple(t.shape)}"
+    return t.stride(1)
+
+
+def conv1d_cl_raw(x, w, bias=None, bias_b=None, res=None, mg_src=None, out=None, lengths=None, dil=1, pad=0, stride=1,
+                  in_slope=1.0, mg_slope=1.0, out_scale=1.0, flags=0, gate_h=0, out2=None):
+    """Launch vits_conv1d_cl.  x [b,t,c_in], w [k,c_out,c_in] (tap-major) in the same dtype; see
+    include/vitsmi.h for the fused prologue/epilogue.  Returns y (allocated unless `out` is given)."""
     _lib.require_cuda(x, w)
-    assert x.is_contiguous() and w.is_contiguous() and x.dtype == w.dtype and x.dim() == 3 and w.dim() == 3
+    assert w.is_contiguous() and x.dtype == w.dtype and w.dim() == 3
     b, t, c_in = x.shape
     k, c_out, c_in_w = w.shape
-    assert c_in_w == c_in
-    t_out = t + 2 * pad - dil * (k - 1)
+    assert c_in_w == c_in, (tuple(x.shape), tuple(w.shape))
+    t_out = (t + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    y_cols = gate_h if (flags & CONV_GATE) else (2 * gate_h if (flags & CONV_GATE_BWD) else c_out)
     if out is None:
         assert not (flags & CONV_ACCUM)
-        out = torch.empty((b, t_out, c_out), device=x.device, dtype=x.dtype)
-    for tns in (res, mg_src, out):
-        assert tns is None or (tns.is_contiguous() and tns.dtype == x.dtype and tuple(tns.shape) == (b, t_out, c_out))
+        out = torch.empty((b, t_out, y_cols), device=x.device, dtype=x.dtype)
+    assert out.dtype == x.dtype and tuple(out.shape) == (b, t_out, y_cols)
+    ldy = _rows(out, "out")
+    for tns, nm in ((res, "res"), (mg_src, "mg_src")):
+        assert tns is None or (tns.dtype == x.dtype and tns.shape[:2] == out.shape[:2] and _rows(tns, nm) == ldy), nm
     for tns in (bias, bias_b):
         assert tns is None or (tns.dtype == torch.float32 and tns.is_contiguous())
     assert lengths is None or lengths.dtype == torch.int32
     p = lambda v: None if v is None else v.data_ptr()
+    d = _lib.ConvDesc(dtype=_DT[x.dtype], b=b, t=t, c_in=c_in, c_out=c_out, k=k, dil=dil, pad=pad, stride=stride, flags=int(flags),
+                      ldx=_rows(x, "x"), ldy=ldy, ldy2=0 if out2 is None else _rows(out2, "out2"), gate_h=gate_h,
+                      in_slope=float(in_slope), mg_slope=float(mg_slope), out_scale=float(out_scale), reserved=0.0,
+                      x=x.data_ptr(), w=w.data_ptr(), bias=p(bias), bias_b=p(bias_b), res=p(res), mg_src=p(mg_src),
+                      y=out.data_ptr(), y2=p(out2), lengths=p(lengths))
+    import ctypes
     e0 = _lib.timer.start("vits_conv1d_cl")
-    rc = _lib.lib().vits_conv1d_cl(_DT[x.dtype], x.data_ptr(), w.data_ptr(), p(bias), p(bias_b), p(res), p(mg_src),
-                                   out.data_ptr(), p(lengths), b, t, c_in, c_out, k, dil, pad,
-                                   float(in_slope), float(mg_slope), float(out_scale), int(flags), _lib.stream_ptr())
+    rc = _lib.lib().vits_conv1d_cl(ctypes.addressof(d), _lib.stream_ptr())
     _lib.timer.stop("vits_conv1d_cl", e0, 2.0 * b * t_out * c_out * c_in * k)       # units = FLOP
     _lib.check(rc, "vits_conv1d_cl")
     return out
@@ -170,14 +187,14 @@ def workspace(nbytes, device):
     return buf
 
 
-def conv1d_cl_wgrad_raw(x, dy, k, lengths=None, dil=1, pad=0, in_slope=1.0, flags=0, out=None):
+def conv1d_cl_wgrad_raw(x, dy, k, lengths=None, dil=1, pad=0, stride=1, in_slope=1.0, flags=0, out=None):
     """dW [k, c_out, c_in] float32 of conv1d_cl_raw(x, w, ...) given dy [b, t_out, c_out]."""
     _lib.require_cuda(x, dy)
-    assert x.is_contiguous() and dy.is_contiguous() and x.dtype == dy.dtype
+    assert x.dtype == dy.dtype
     b, t, c_in = x.shape
     c_out = dy.shape[2]
-    t_out = t + 2 * pad - dil * (k - 1)
-    assert tuple(dy.shape) == (b, t_out, c_out)
+    t_out = (t + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    assert tuple(dy.shape[:2]) == (b, t_out), (tuple(x.shape), tuple(dy.shape))
     if out is None:
         assert not (flags & CONV_ACCUM)
         out = torch.empty((k, c_out, c_in), device=x.device, dtype=torch.float32)
@@ -185,10 +202,13 @@ def conv1d_cl_wgrad_raw(x, dy, k, lengths=None, dil=1, pad=0, in_slope=1.0, flag
     L = _lib.lib()
     ws_bytes = L.vits_conv1d_cl_wgrad_workspace(b, t_out, c_in, c_out, k)
     ws = workspace(ws_bytes, x.device)
+    d = _lib.WgradDesc(dtype=_DT[x.dtype], b=b, t=t, c_in=c_in, c_out=c_out, k=k, dil=dil, pad=pad, stride=stride, flags=int(flags),
+                       ldx=_rows(x, "x"), lddy=_rows(dy, "dy"), in_slope=float(in_slope), reserved=0.0,
+                       x=x.data_ptr(), dy=dy.data_ptr(), dw=out.data_ptr(), workspace=ws.data_ptr(), workspace_bytes=ws.numel(),
+                       lengths=None if lengths is None else lengths.data_ptr())
+    import ctypes
     e0 = _lib.timer.start("vits_conv1d_cl_wgrad")
-    rc = L.vits_conv1d_cl_wgrad(_DT[x.dtype], x.data_ptr(), dy.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(),
-                                None if lengths is None else lengths.data_ptr(), b, t, c_in, c_out, k, dil, pad,
-                                float(in_slope), int(flags), _lib.stream_ptr())
+    rc = L.vits_conv1d_cl_wgrad(ctypes.addressof(d), _lib.stream_ptr())
     _lib.timer.stop("vits_conv1d_cl_wgrad", e0, 2.0 * b * t_out * c_out * c_in * k)
     _lib.check(rc, "vits_conv1d_cl_wgrad")
     return out

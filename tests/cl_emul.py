@@ -5,8 +5,8 @@ import torch
 import torch.nn.functional as F
 
 
-def conv1d_cl_raw(x, w, bias=None, bias_b=None, res=None, mg_src=None, out=None, lengths=None, dil=1, pad=0,
-                  in_slope=1.0, mg_slope=1.0, out_scale=1.0, flags=0):
+def conv1d_cl_raw(x, w, bias=None, bias_b=None, res=None, mg_src=None, out=None, lengths=None, dil=1, pad=0, stride=1,
+                  in_slope=1.0, mg_slope=1.0, out_scale=1.0, flags=0, gate_h=0, out2=None):
     b, t, c_in = x.shape
     k, c_out, c_in_w = w.shape
     assert c_in_w == c_in, (tuple(x.shape), tuple(w.shape))
@@ -15,25 +15,39 @@ def conv1d_cl_raw(x, w, bias=None, bias_b=None, res=None, mg_src=None, out=None,
         xf = xf * (torch.arange(t, device=x.device)[None, :, None] < lengths[:, None, None])
     if in_slope != 1.0:
         xf = F.leaky_relu(xf, in_slope)
-    v = F.conv1d(xf.transpose(1, 2), w.float().permute(1, 2, 0), None, 1, pad, dil).transpose(1, 2)
+    v = F.conv1d(xf.transpose(1, 2), w.float().permute(1, 2, 0), None, stride, pad, dil).transpose(1, 2)
     if bias is not None:
         v = v + bias
     if bias_b is not None:
         v = v + bias_b[:, None, :]
-    after = bool(flags & 16)
-    if res is not None and not after:
-        v = v + res.float()
-    v = v * out_scale
-    if mg_src is not None:
-        v = v * torch.where(mg_src.float() > 0, 1.0, mg_slope)
-    if res is not None and after:
-        v = v + res.float()
-    if flags & 4:
-        v = torch.tanh(v)
-    if flags & 2:
-        v = v * (torch.arange(v.size(1), device=x.device)[None, :, None] < lengths[:, None, None])
-    if flags & 8:
-        v = v + out.float()
+    rowmask = None
+    if lengths is not None:
+        rowmask = (torch.arange(v.size(1), device=x.device)[None, :, None] < lengths[:, None, None])
+    if flags & 32:                                                     # GATE
+        if out2 is not None:
+            out2.copy_(v.to(x.dtype))
+        v = torch.tanh(v[..., :gate_h]) * torch.sigmoid(v[..., gate_h:])
+    else:
+        after = bool(flags & 16)
+        if res is not None and not after:
+            v = v + res.float()
+        v = v * out_scale
+        if flags & 64:                                                 # GATE_BWD
+            ta, sb = torch.tanh(mg_src.float()[..., :gate_h]), torch.sigmoid(mg_src.float()[..., gate_h:])
+            v = torch.cat([v * sb * (1 - ta * ta), v * ta * sb * (1 - sb)], -1)
+            if flags & 2:
+                v = v * rowmask
+        else:
+            if mg_src is not None:
+                v = v * torch.where(mg_src.float() > 0, 1.0, mg_slope)
+            if res is not None and after:
+                v = v + res.float()
+            if flags & 4:
+                v = torch.tanh(v)
+            if flags & 2:
+                v = v * rowmask
+            if flags & 8:
+                v = v + out.float()
     v = v.to(x.dtype)
     if out is not None:
         out.copy_(v)
@@ -41,7 +55,7 @@ def conv1d_cl_raw(x, w, bias=None, bias_b=None, res=None, mg_src=None, out=None,
     return v
 
 
-def conv1d_cl_wgrad_raw(x, dy, k, lengths=None, dil=1, pad=0, in_slope=1.0, flags=0, out=None):
+def conv1d_cl_wgrad_raw(x, dy, k, lengths=None, dil=1, pad=0, stride=1, in_slope=1.0, flags=0, out=None):
     b, t, c_in = x.shape
     c_out = dy.shape[2]
     w = torch.zeros(k, c_out, c_in, device=x.device, requires_grad=True)
@@ -53,7 +67,7 @@ def conv1d_cl_wgrad_raw(x, dy, k, lengths=None, dil=1, pad=0, in_slope=1.0, flag
     if in_slope != 1.0:
         xf = F.leaky_relu(xf, in_slope)
     with torch.enable_grad():
-        y = F.conv1d(xf.transpose(1, 2), w.permute(1, 2, 0), None, 1, pad, dil).transpose(1, 2)
+        y = F.conv1d(xf.transpose(1, 2), w.permute(1, 2, 0), None, stride, pad, dil).transpose(1, 2)
         (g,) = torch.autograd.grad(y, w, dyf)
     if out is not None:
         if flags & 8:

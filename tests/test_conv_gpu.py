@@ -132,3 +132,51 @@ def test_weight_gradient_is_reproducible(pkg):
     a = pkg.kernels.conv1d_cl_wgrad_raw(x, dy, 7, dil=1, pad=3).clone()
     b = pkg.kernels.conv1d_cl_wgrad_raw(x, dy, 7, dil=1, pad=3)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-5), (torch.bfloat16, 1.5e-2)])
+def test_emulation_agrees_on_new_modes(pkg, dtype, tol):
+    """Gate / gate-backward epilogues, channel-sliced operands (row pitches) and time stride: the HIP kernel
+    against tests/cl_emul.py (the torch statement of include/vitsmi.h used by the CPU logic tests)."""
+    import cl_emul
+    K = pkg.kernels
+    torch.manual_seed(11)
+    b, t, H, k = 3, 150, 192, 5
+    lens = torch.tensor([150, 99, 17], device=DEV, dtype=torch.int32)
+    wide = torch.randn(b, t, 2 * H, device=DEV).to(dtype)
+    x = wide[..., H:]                                              # channel slice: ldx = 2H
+    w = (torch.randn(k, 2 * H, H, device=DEV) / (H * k) ** 0.5).to(dtype)
+    bias, bias_b = torch.randn(2 * H, device=DEV), torch.randn(b, 2 * H, device=DEV)
+    kw = dict(bias=bias, bias_b=bias_b, pad=2, flags=K.CONV_GATE, gate_h=H)
+    pre_a = torch.empty(b, t, 2 * H, device=DEV, dtype=dtype); pre_b = torch.empty_like(pre_a)
+    ya = K.conv1d_cl_raw(x, w, out2=pre_a, **kw)
+    yb = cl_emul.conv1d_cl_raw(x, w, out2=pre_b, **kw)
+    assert rel(ya, yb) < tol and rel(pre_a, pre_b) < tol
+    # gate backward: 1x1 conv producing d(acts) from a 2H-wide gradient, chain rule through the gate
+    w1 = (torch.randn(1, H, 2 * H, device=DEV) / (2 * H) ** 0.5).to(dtype)
+    d_rs = torch.randn(b, t, 2 * H, device=DEV).to(dtype)
+    kw = dict(mg_src=pre_b, lengths=lens, flags=K.CONV_GATE_BWD | K.CONV_MASK_OUT, gate_h=H)
+    assert rel(K.conv1d_cl_raw(d_rs, w1, **kw), cl_emul.conv1d_cl_raw(d_rs, w1, **kw)) < tol
+    # output into a channel slice of a wider tensor, residual read from the same slice (in place)
+    buf_a = torch.randn(b, t, 2 * H, device=DEV).to(dtype); buf_b = buf_a.clone()
+    w2 = (torch.randn(3, H, H, device=DEV) / (3 * H) ** 0.5).to(dtype)
+    src = torch.randn(b, t, H, device=DEV).to(dtype)
+    K.conv1d_cl_raw(src, w2, res=buf_a[..., :H], out=buf_a[..., :H], pad=1, flags=K.CONV_RES_AFTER)
+    cl_emul.conv1d_cl_raw(src, w2, res=buf_b[..., :H].clone(), out=buf_b[..., :H], pad=1, flags=K.CONV_RES_AFTER)
+    assert rel(buf_a, buf_b) < tol
+    # time stride (discriminator-style): k=5 stride 3 and k=41 stride 4
+    for (kk, st, pd, ci, co) in [(5, 3, 2, 32, 128), (41, 4, 20, 64, 64)]:
+        xs = torch.randn(2, 500, ci, device=DEV).to(dtype)
+        ws = (torch.randn(kk, co, ci, device=DEV) / (ci * kk) ** 0.5).to(dtype)
+        ya, yb = K.conv1d_cl_raw(xs, ws, pad=pd, stride=st, in_slope=0.1), cl_emul.conv1d_cl_raw(xs, ws, pad=pd, stride=st, in_slope=0.1)
+        assert ya.shape == yb.shape and rel(ya, yb) < tol
+        if kk == 5:
+            dy = torch.randn_like(ya)
+            ga = K.conv1d_cl_wgrad_raw(xs, dy, kk, pad=pd, stride=st, in_slope=0.1)
+            gb = cl_emul.conv1d_cl_wgrad_raw(xs, dy, kk, pad=pd, stride=st, in_slope=0.1)
+            assert rel(ga, gb) < tol
+    # weight gradient with channel-sliced x and dy
+    dyw = torch.randn(b, t, 2 * H, device=DEV).to(dtype)
+    ga = K.conv1d_cl_wgrad_raw(wide[..., :H], dyw[..., H:], 1)
+    gb = cl_emul.conv1d_cl_wgrad_raw(wide[..., :H], dyw[..., H:], 1)
+    assert rel(ga, gb) < tol

@@ -37,6 +37,26 @@ def main():
     busy = sum(v[1] for v in agg.values()) / a.steps
     print(f"# steady-state window: {a.steps} steps, wall {wall/1e6:.3f} ms/step, kernel-busy {busy/1e6:.3f} ms/step, "
           f"{len(win)/a.steps:.0f} launches/step, {len(agg)} distinct kernels")
+    cats = collections.OrderedDict([
+        ("hip: this repo's kernels", ("conv1d_cl", "wgrad_kernel", "reduce_slabs", "fold_kernel", "unfold_kernel", "mas_kernel", "vits_")),
+        ("MIOpen convolution (+layout/im2col helpers)", ("igemm_", "naive_conv", "ck::", "_ZN2ck", "Im2d2Col", "Col2Im", "batched_transpose", "SubTensorOp", "miopen", "Im3d", "gridwise")),
+        ("rocBLAS/hipBLASLt GEMM", ("Cijk_",)),
+        ("aten elementwise/copy/cast", ("elementwise_kernel", "vectorized_elementwise", "CatArrayBatchedCopy", "index", "fill", "copy")),
+        ("aten reductions/norms", ("reduce_kernel", "layer_norm", "softmax", "cunn_", "RowwiseMoments", "norm")),
+        ("optimizer (multi-tensor)", ("multi_tensor_apply",)),
+        ("FFT", ("fft", "rocfft", "transpose_kernel", "real_post", "r2c", "c2r")),
+    ])
+    ctot = collections.OrderedDict((k, [0, 0]) for k in list(cats) + ["other"])
+    for n, (c, t) in agg.items():
+        for cat, pats in cats.items():
+            if any(p_ in n for p_ in pats):
+                ctot[cat][0] += c; ctot[cat][1] += t
+                break
+        else:
+            ctot["other"][0] += c; ctot["other"][1] += t
+    print("# by category:")
+    for cat, (c, t) in ctot.items():
+        print(f"#   {t/a.steps/1e6:9.3f} ms/step {100*t/a.steps/busy:6.2f}%  {c/a.steps:8.0f} launches/step  {cat}")
     print(f"# {'ms/step':>9} {'share':>7} {'calls/step':>10} {'avg_us':>9}  kernel")
     for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[: a.top]:
         print(f"  {t/a.steps/1e6:9.3f} {100*t/a.steps/busy:6.2f}% {c/a.steps:10.1f} {t/c/1e3:9.1f}  {n[:120]}")
