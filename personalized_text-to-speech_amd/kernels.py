@@ -19,9 +19,9 @@ from . import monotonic_align as _ma
 BACKENDS = {
     "maximum_path": "hip",
     "decoder (Generator: conv_pre, ups, ResBlocks, conv_post; fwd+bwd)": "hip",
-    "conv1d (other modules)": "rocm",
+    "posterior encoder + flow (1x1 pre/post/proj, gated WN stacks; fwd+bwd)": "hip",
+    "conv1d (text encoder, duration predictor, discriminators)": "rocm",
     "weight_norm": "rocm",
-    "wn_gate": "rocm",
     "layer_norm_c": "rocm",
     "rel_attention": "rocm",
     "rq_spline": "rocm",

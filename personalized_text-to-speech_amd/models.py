@@ -147,13 +147,24 @@ class ResidualCouplingBlock(nn.Module):
             self.flows.append(modules.Flip())
 
     def forward(self, x, x_mask, g=None, reverse=False):
+        """x [b, c, t] -> [b, c, t].  The four coupling layers and the channel flips between them run
+        channels-last ([b, t, c]) without leaving that layout."""
+        mask_cl = x_mask.transpose(1, 2)
+        lengths = x_mask[:, 0, :].sum(-1).to(torch.int32)
+        h = x.transpose(1, 2).contiguous()
         if not reverse:
             for flow in self.flows:
-                x, _ = flow(x, x_mask, g=g, reverse=reverse)
+                if isinstance(flow, modules.Flip):
+                    h = torch.flip(h, [2])
+                else:
+                    h, _ = flow.forward_cl(h, lengths, mask_cl, g=g, reverse=False)
         else:
             for flow in reversed(self.flows):
-                x = flow(x, x_mask, g=g, reverse=reverse)
-        return x
+                if isinstance(flow, modules.Flip):
+                    h = torch.flip(h, [2])
+                else:
+                    h = flow.forward_cl(h, lengths, mask_cl, g=g, reverse=True)
+        return h.transpose(1, 2)
 
 
 class PosteriorEncoder(nn.Module):
@@ -167,13 +178,22 @@ class PosteriorEncoder(nn.Module):
         self.proj = Conv1d(hidden_channels, out_channels * 2, 1)
 
     def forward(self, x, x_lengths, g=None):
+        """x [b, spec_channels, t] -> z, m, logs [b, c, t] (transposed views of channels-last results), x_mask."""
+        from . import wn_cl
         x_mask = torch.unsqueeze(commons.sequence_mask(x_lengths, x.size(2)), 1).to(x.dtype)
-        x = self.pre(x) * x_mask
-        x = self.enc(x, x_mask, g=g)
-        stats = self.proj(x) * x_mask
-        m, logs = torch.split(stats, self.out_channels, dim=1)
-        z = (m + noise.randn_like(m) * torch.exp(logs)) * x_mask
-        return z, m, logs, x_mask
+        lengths = x_lengths.to(torch.int32)
+        dtype = wn_cl.compute_dtype()
+        # channels last, input channels padded to the kernels' vector width (zero weights on the pad)
+        cin = self.in_channels
+        cpad = (-cin) % 8
+        x_cl = torch.nn.functional.pad(x.transpose(1, 2), (0, cpad)).to(dtype).contiguous()
+        w_pre = torch.nn.functional.pad(self.pre.weight, (0, 0, 0, cpad))
+        h = wn_cl.conv_cl(x_cl, wn_cl.prep_conv(w_pre), self.pre.bias, lengths, mask_out=True)
+        h = wn_cl.wn_forward_cl(self.enc, h, lengths, g)
+        stats = wn_cl.conv_cl(h, wn_cl.prep_conv(self.proj.weight), self.proj.bias, lengths, mask_out=True).float()
+        m, logs = stats[..., :self.out_channels], stats[..., self.out_channels:]
+        z = (m + noise.randn_like(m.transpose(1, 2)).transpose(1, 2) * torch.exp(logs)) * x_mask.transpose(1, 2)
+        return z.transpose(1, 2), m.transpose(1, 2), logs.transpose(1, 2), x_mask
 
 
 class Generator(nn.Module):

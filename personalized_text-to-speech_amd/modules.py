@@ -157,22 +157,11 @@ class WN(nn.Module):
             self.res_skip_layers.append(WNConv1d(hidden_channels, res_skip_channels, 1))
 
     def forward(self, x, x_mask, g=None, **kwargs):
-        H = self.hidden_channels
-        output = None
-        if g is not None:
-            g = self.cond_layer(g)                                     # [b, 2*H*L, 1]
-        for i in range(self.n_layers):
-            x_in = self.in_layers[i](x)
-            g_l = g[:, i * 2 * H:(i + 1) * 2 * H, :] if g is not None else None
-            acts = self.drop(K.wn_gate(x_in, g_l, H))
-            res_skip = self.res_skip_layers[i](acts)
-            if i < self.n_layers - 1:
-                x = (x + res_skip[:, :H, :]) * x_mask
-                skip = res_skip[:, H:, :]
-            else:
-                skip = res_skip
-            output = skip if output is None else output + skip
-        return output * x_mask
+        """x [b, H, t] (reference layout, zero beyond the mask) -> output * x_mask.  Runs as one
+        autograd node over the channels-last HIP kernels (wn_cl.WNFn)."""
+        from . import wn_cl
+        out = wn_cl.wn_forward_cl(self, x.transpose(1, 2).contiguous(), wn_cl.lengths_of(x_mask), g)
+        return out.transpose(1, 2).to(x.dtype)
 
 
 class ResBlock1(nn.Module):
@@ -271,19 +260,31 @@ class ResidualCouplingLayer(nn.Module):
         self.post.bias.data.zero_()
 
     def forward(self, x, x_mask, g=None, reverse=False):
-        x0, x1 = torch.split(x, [self.half_channels] * 2, 1)
-        h = self.pre(x0) * x_mask
-        h = self.enc(h, x_mask, g=g)
-        stats = self.post(h) * x_mask
-        if not self.mean_only:
-            m, logs = torch.split(stats, [self.half_channels] * 2, 1)
-        else:
-            m, logs = stats, torch.zeros_like(stats)
+        y = self.forward_cl(x.transpose(1, 2).contiguous(), None, x_mask.transpose(1, 2), g, reverse)
         if not reverse:
-            x1 = m + x1 * torch.exp(logs) * x_mask
-            return torch.cat([x0, x1], 1), torch.sum(logs, [1, 2])
-        x1 = (x1 - m) * torch.exp(-logs) * x_mask
-        return torch.cat([x0, x1], 1)
+            return y[0].transpose(1, 2), y[1]
+        return y.transpose(1, 2)
+
+    def forward_cl(self, x, lengths, mask_cl, g=None, reverse=False):
+        """x [b, t, channels] channels-last; mask_cl [b, t, 1].  pre / WN / post run on the HIP kernels."""
+        from . import wn_cl
+        if lengths is None:
+            lengths = mask_cl[:, :, 0].sum(-1).to(torch.int32)
+        half = self.half_channels
+        x0, x1 = x[..., :half], x[..., half:]
+        h = wn_cl.conv_cl(x0, wn_cl.prep_conv(self.pre.weight), self.pre.bias, lengths, mask_out=True)
+        h = wn_cl.wn_forward_cl(self.enc, h, lengths, g)
+        stats = wn_cl.conv_cl(h, wn_cl.prep_conv(self.post.weight), self.post.bias, lengths, mask_out=True).to(x.dtype)
+        if not self.mean_only:
+            m, logs = stats[..., :half], stats[..., half:]
+        else:
+            m, logs = stats, None
+        if not reverse:
+            x1 = m + (x1 * torch.exp(logs) if logs is not None else x1) * mask_cl
+            logdet = torch.sum(logs, [1, 2]) if logs is not None else torch.zeros(x.size(0), dtype=x.dtype, device=x.device)
+            return torch.cat([x0, x1], -1), logdet
+        x1 = (x1 - m) * (torch.exp(-logs) if logs is not None else 1.0) * mask_cl
+        return torch.cat([x0, x1], -1)
 
 
 class ConvFlow(nn.Module):

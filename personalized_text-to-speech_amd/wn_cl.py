@@ -1,0 +1,186 @@
+"""Channels-last building blocks on the HIP convolution kernels: a differentiable fused
+convolution (`conv_cl`) and the gated WaveNet stack of the reference (modules.WN, modules.py:111-184)
+as one autograd node with a hand-written backward.
+
+WN layer i in the reference graph (modules.py:157-176, commons.py:103-110)       here
+----------------------------------------------------------------------------  ---------------------------
+x_in = in_layers[i](x)  (+ bias)                                               conv k, GATE epilogue:
+g_l  = g[:, i*2H:(i+1)*2H]                                                        bias_b = cond[i] (per item),
+acts = tanh((x_in+g_l)[:, :H]) * sigmoid((x_in+g_l)[:, H:])                       y = acts, y2 = pre-activations
+res_skip = res_skip_layers[i](acts)                                            two 1x1 convs on acts:
+x = (x + res_skip[:, :H]) * x_mask                                                res  -> `res` + MASK_OUT epilogue
+output = output + res_skip[:, H:]          ... return output * x_mask             skip -> MASK_OUT + ACCUM into `output`
+"""
+import torch
+
+from . import _lib
+from . import kernels as K
+
+
+def flip_t(w):
+    """[k][co][ci] -> data-gradient weights [k][ci][co] with the taps reversed."""
+    return w.flip(0).transpose(1, 2).contiguous()
+
+
+def lengths_of(mask):
+    """int32 [b] valid lengths of a prefix mask [b, 1, t] (commons.sequence_mask output)."""
+    return mask[:, 0, :].sum(-1).to(torch.int32)
+
+
+def compute_dtype():
+    return torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
+
+
+def prep_conv(weight):
+    """torch Conv1d weight [c_out, c_in, k] -> kernel layout [k][c_out][c_in] (fp32, autograd-connected)."""
+    return weight.permute(2, 0, 1).contiguous()
+
+
+class ConvCLFn(torch.autograd.Function):
+    """y = mask_out( conv(lrelu_slope(mask_in(x)), w) + bias ), x [b,t,c_in] channels-last (may be a channel
+    slice), w [k][c_out][c_in] fp32 kernel layout.  Data and weight gradients by the same HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, dtype, x, w, bias, lengths, dil, pad, in_slope, mask_in, mask_out):
+        xd = x.detach()
+        if xd.dtype != dtype:
+            xd = xd.to(dtype)
+        wd = w.detach().to(dtype)
+        flags = (K.CONV_MASK_IN if mask_in else 0) | (K.CONV_MASK_OUT if mask_out else 0)
+        y = K.conv1d_cl_raw(xd, wd, None if bias is None else bias.detach().float(), lengths=lengths, dil=dil, pad=pad,
+                            in_slope=in_slope, flags=flags)
+        ctx.save_for_backward(xd, wd)
+        ctx.lengths, ctx.cfg, ctx.has_bias, ctx.x_dtype = lengths, (dil, pad, in_slope, mask_in, mask_out), bias is not None, x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xd, wd = ctx.saved_tensors
+        dil, pad, in_slope, mask_in, mask_out = ctx.cfg
+        k = wd.size(0)
+        dy = dy.contiguous()
+        if mask_out:                                    # d(y * mask): zero rows first (one pass, reused three times)
+            t = dy.size(1)
+            dy = dy * (torch.arange(t, device=dy.device)[None, :, None] < ctx.lengths[:, None, None])
+        dw = K.conv1d_cl_wgrad_raw(xd, dy, k, lengths=ctx.lengths, dil=dil, pad=pad, in_slope=in_slope,
+                                   flags=K.CONV_MASK_IN if mask_in else 0)
+        db = dy.sum((0, 1), dtype=torch.float32) if ctx.has_bias else None
+        dx = None
+        if ctx.needs_input_grad[1]:
+            xs = xd if xd.is_contiguous() else xd.contiguous()
+            dx = K.conv1d_cl_raw(dy, flip_t(wd), None, mg_src=xs if in_slope != 1.0 else None, lengths=ctx.lengths, dil=dil,
+                                 pad=dil * (k - 1) - pad, mg_slope=in_slope, flags=K.CONV_MASK_OUT if mask_in else 0)
+            if dx.dtype != ctx.x_dtype:
+                dx = dx.to(ctx.x_dtype)
+        return None, dx, dw, db, None, None, None, None, None, None
+
+
+def conv_cl(x, w, bias=None, lengths=None, dil=1, pad=0, in_slope=1.0, mask_in=False, mask_out=False, dtype=None):
+    return ConvCLFn.apply(dtype or compute_dtype(), x, w, bias, lengths, dil, pad, in_slope, mask_in, mask_out)
+
+
+class WNPlan:
+    def __init__(self, wn):
+        self.H, self.k, self.L = wn.hidden_channels, wn.kernel_size[0], wn.n_layers
+        self.dils = [wn.dilation_rate ** i for i in range(self.L)]
+        self.has_cond = wn.gin_channels != 0
+
+
+def wn_prepared_weights(wn):
+    out = []
+    for i in range(wn.n_layers):
+        out += [prep_conv(wn.in_layers[i].weight), wn.in_layers[i].bias,
+                prep_conv(wn.res_skip_layers[i].weight), wn.res_skip_layers[i].bias]
+    return out
+
+
+def wn_cond(wn, g, n_items):
+    """cond_layer(g) (modules.py:152-153) as [L][b][2H] float32, or None."""
+    if g is None:
+        return None
+    c = torch.nn.functional.linear(g[:, :, 0].float(), wn.cond_layer.weight[:, :, 0].float(), wn.cond_layer.bias.float())
+    return c.view(n_items, wn.n_layers, 2 * wn.hidden_channels).transpose(0, 1).contiguous()
+
+
+class WNFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, plan, dtype, x, lengths, cond, *wb):
+        """x [b,t,H] channels-last with rows >= lengths already zero; cond [L][b][2H] fp32 or None."""
+        C = K.conv1d_cl_raw
+        H, L, k = plan.H, plan.L, plan.k
+        w = [t.detach().to(dtype) if t.dim() == 3 else t.detach().float() for t in wb]
+        h = x.detach().to(dtype).contiguous()
+        cd = None if cond is None else cond.detach().float().contiguous()
+        out = torch.empty_like(h)
+        saved = []
+        for i in range(L):
+            w_in, b_in, w_rs, b_rs = w[4 * i: 4 * i + 4]
+            d = plan.dils[i]
+            pre = torch.empty(h.size(0), h.size(1), 2 * H, device=h.device, dtype=dtype)
+            acts = C(h, w_in, b_in, bias_b=None if cd is None else cd[i], dil=d, pad=(k * d - d) // 2,
+                     flags=K.CONV_GATE, gate_h=H, out2=pre)
+            acc = K.CONV_ACCUM if i > 0 else 0
+            if i < L - 1:
+                h_next = C(acts, w_rs[:, :H], b_rs[:H], res=h, lengths=lengths, flags=K.CONV_MASK_OUT)
+                C(acts, w_rs[:, H:], b_rs[H:], out=out, lengths=lengths, flags=K.CONV_MASK_OUT | acc)
+            else:
+                h_next = None
+                C(acts, w_rs, b_rs, out=out, lengths=lengths, flags=K.CONV_MASK_OUT | acc)
+            saved += [h, pre, acts]
+            h = h_next
+        ctx.plan, ctx.dtype, ctx.lengths, ctx.has_cond, ctx.n_saved = plan, dtype, lengths, cd is not None, len(saved)
+        ctx.save_for_backward(*saved, *w)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        plan, dtype, lengths = ctx.plan, ctx.dtype, ctx.lengths
+        C, WG = K.conv1d_cl_raw, K.conv1d_cl_wgrad_raw
+        H, L, k = plan.H, plan.L, plan.k
+        saved = list(ctx.saved_tensors[: ctx.n_saved])
+        w = list(ctx.saved_tensors[ctx.n_saved:])
+        grads = [None] * len(w)
+        t = d_out.size(1)
+        rowmask = (torch.arange(t, device=d_out.device)[None, :, None] < lengths[:, None, None])
+        d_o = (d_out * rowmask).to(dtype).contiguous()          # d(output * x_mask)
+        s_o = d_o.sum((0, 1), dtype=torch.float32)
+        dcond = [] if ctx.has_cond else None
+        d_h = None
+        for i in reversed(range(L)):
+            acts, pre, h = saved.pop(), saved.pop(), saved.pop()
+            w_in, b_in, w_rs, b_rs = w[4 * i: 4 * i + 4]
+            d = plan.dils[i]
+            pad = (k * d - d) // 2
+            if i == L - 1:
+                grads[4 * i + 2] = WG(acts, d_o, 1)
+                grads[4 * i + 3] = s_o
+                d_pre = C(d_o, flip_t(w_rs), None, mg_src=pre, lengths=lengths, flags=K.CONV_GATE_BWD | K.CONV_MASK_OUT, gate_h=H)
+            else:
+                dw_rs = torch.empty(1, 2 * H, H, device=d_o.device, dtype=torch.float32)
+                WG(acts, d_h, 1, out=dw_rs[:, :H])
+                WG(acts, d_o, 1, out=dw_rs[:, H:])
+                grads[4 * i + 2] = dw_rs
+                grads[4 * i + 3] = torch.cat([d_h.sum((0, 1), dtype=torch.float32), s_o])
+                # partial d(acts) from the residual branch, held in the left half of a 2H-wide buffer so that
+                # its row pitch equals that of the GATE_BWD output (the kernel shares ldy between y, res, mg_src)
+                tmp = torch.empty_like(pre)[..., :H]
+                C(d_h, flip_t(w_rs[:, :H]), None, out=tmp)
+                d_pre = C(d_o, flip_t(w_rs[:, H:]), None, res=tmp, mg_src=pre, lengths=lengths,
+                          flags=K.CONV_GATE_BWD | K.CONV_MASK_OUT, gate_h=H)
+            grads[4 * i] = WG(h, d_pre, k, dil=d, pad=pad)
+            s_b = d_pre.sum(1, dtype=torch.float32)                       # [b, 2H]: gradient of cond[i]
+            grads[4 * i + 1] = s_b.sum(0)
+            if dcond is not None:
+                dcond.append(s_b)
+            d_h = C(d_pre, flip_t(w_in), None, res=d_h, lengths=lengths, dil=d, pad=pad,
+                    flags=K.CONV_MASK_OUT | (K.CONV_RES_AFTER if d_h is not None else 0))
+        dc = torch.stack(dcond[::-1], 0) if dcond is not None else None
+        return (None, None, d_h, None, dc, *grads)
+
+
+def wn_forward_cl(wn, x_cl, lengths, g):
+    """modules.WN.forward on channels-last x [b,t,H] (rows >= lengths zero)."""
+    if getattr(wn, "_plan", None) is None:
+        wn._plan = WNPlan(wn)
+    cond = wn_cond(wn, g, x_cl.size(0))
+    return WNFn.apply(wn._plan, compute_dtype(), x_cl, lengths, cond, *wn_prepared_weights(wn))

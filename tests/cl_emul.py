@@ -10,6 +10,11 @@ def conv1d_cl_raw(x, w, bias=None, bias_b=None, res=None, mg_src=None, out=None,
     b, t, c_in = x.shape
     k, c_out, c_in_w = w.shape
     assert c_in_w == c_in, (tuple(x.shape), tuple(w.shape))
+    # the kernel shares one row pitch between y, res and mg_src: enforce it here too
+    y_cols = gate_h if (flags & 32) else (2 * gate_h if (flags & 64) else c_out)
+    ldy = out.stride(1) if out is not None else y_cols
+    for tns in (res, mg_src):
+        assert tns is None or tns.stride(1) == ldy, "res / mg_src row pitch must equal the output's"
     xf = x.float()
     if flags & 1:
         xf = xf * (torch.arange(t, device=x.device)[None, :, None] < lengths[:, None, None])
@@ -48,7 +53,7 @@ def conv1d_cl_raw(x, w, bias=None, bias_b=None, res=None, mg_src=None, out=None,
                 v = v * rowmask
             if flags & 8:
                 v = v + out.float()
-    v = v.to(x.dtype)
+    v = v.to(x.dtype).contiguous()                  # the kernel always writes dense rows
     if out is not None:
         out.copy_(v)
         return out

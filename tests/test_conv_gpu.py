@@ -162,7 +162,7 @@ def test_emulation_agrees_on_new_modes(pkg, dtype, tol):
     w2 = (torch.randn(3, H, H, device=DEV) / (3 * H) ** 0.5).to(dtype)
     src = torch.randn(b, t, H, device=DEV).to(dtype)
     K.conv1d_cl_raw(src, w2, res=buf_a[..., :H], out=buf_a[..., :H], pad=1, flags=K.CONV_RES_AFTER)
-    cl_emul.conv1d_cl_raw(src, w2, res=buf_b[..., :H].clone(), out=buf_b[..., :H], pad=1, flags=K.CONV_RES_AFTER)
+    cl_emul.conv1d_cl_raw(src, w2, res=buf_b[..., :H], out=buf_b[..., :H], pad=1, flags=K.CONV_RES_AFTER)
     assert rel(buf_a, buf_b) < tol
     # time stride (discriminator-style): k=5 stride 3 and k=41 stride 4
     for (kk, st, pd, ci, co) in [(5, 3, 2, 32, 128), (41, 4, 20, 64, 64)]:
