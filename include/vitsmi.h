@@ -161,6 +161,36 @@ int vits_convt_fold_cl(int dtype, const void* p, const float* bias, void* y, int
 int vits_convt_unfold_cl(int dtype, const void* dy, void* dp, int b, int t_in, int c_out, int k, int u, int pad,
                          void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Multi-tensor weight preparation (weight-norm + kernel layouts + compute dtype) and its backward.
+ *
+ * Replaces: the per-forward weight_norm recomputation of every wrapped convolution
+ *           (torch.nn.utils.weight_norm hooks: models.py:254,304-312,339-348; modules.py:128,135,145,
+ *           191-206,236-239) and autograd's backward through it — one launch per GROUP of layers
+ *           instead of ~8 small kernels per layer.
+ *   entries  device array, one per (slice of a) convolution weight, sorted by row0:
+ *     v        fp32 master weight in torch layout: Conv1d [c_out_total][c_in][k] (layout 0) or
+ *              ConvTranspose1d [c_in_total][c_out][k] (layout 1);   g  weight_g [rows_total] or NULL;
+ *     row_lo   first weight-norm row of the parameter covered by this entry, n_rows rows are covered
+ *              (layout 0: rows are output channels, c_out = n_rows; layout 1: rows are input channels);
+ *     c_out_p / c_in_p   padded channel counts of the emitted operands (zero outside; pad areas are
+ *              never written, allocate the arenas zeroed);
+ *     off      element offset of this entry in w_fwd / w_bwd / dw;  off_dv / off_dg  element offsets of
+ *              the parameter's gradients in dparam;  row0  global index of the entry's first row.
+ *   w_fwd   [k][c_out_p][c_in_p] (layout 1: [1][k*c_out][c_in_p]),  w_bwd [k][c_in_p][c_out_p] taps
+ *           reversed (layout 1: [1][c_in][k*c_out]), both in `dtype`;  dw fp32 in the w_fwd layout.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct vits_prep_entry {
+  const float* v;  const float* g;
+  int64_t off, off_dv, off_dg;
+  int32_t layout, c_out, c_in, k, c_out_p, c_in_p, row_lo, n_rows, row0, reserved;
+} vits_prep_entry;
+
+int vits_weight_prep(const vits_prep_entry* entries, int n_entries, int total_rows, int dtype, void* w_fwd,
+                     void* w_bwd, void* stream);
+int vits_weight_prep_bwd(const vits_prep_entry* entries, int n_entries, int total_rows, const float* dw,
+                         float* dparam, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

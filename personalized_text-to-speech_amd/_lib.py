@@ -23,6 +23,8 @@ SIGNATURES = {
     "vits_abi_version": (c_int, []),
     "vits_last_error": (ctypes.c_char_p, []),
     "vits_mas_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "vits_weight_prep": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "vits_weight_prep_bwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "vits_convt_fold_cl": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "vits_convt_unfold_cl": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "vits_conv1d_cl_wgrad_workspace": (c_size_t, [c_int] * 5),
@@ -36,6 +38,12 @@ class ConvDesc(ctypes.Structure):
                                               "ldx", "ldy", "ldy2", "gate_h")] + \
                [(n, c_float) for n in ("in_slope", "mg_slope", "out_scale", "reserved")] + \
                [(n, c_void_p) for n in ("x", "w", "bias", "bias_b", "res", "mg_src", "y", "y2", "lengths")]
+
+
+class PrepEntry(ctypes.Structure):
+    """vits_prep_entry of include/vitsmi.h"""
+    _fields_ = [("v", c_void_p), ("g", c_void_p), ("off", ctypes.c_int64), ("off_dv", ctypes.c_int64), ("off_dg", ctypes.c_int64)] + \
+               [(n, ctypes.c_int32) for n in ("layout", "c_out", "c_in", "k", "c_out_p", "c_in_p", "row_lo", "n_rows", "row0", "reserved")]
 
 
 class WgradDesc(ctypes.Structure):

@@ -1,0 +1,132 @@
+// Multi-tensor weight preparation: ONE launch turns the fp32 master parameters of a whole group of
+// convolutions into the matrix-core kernels' operands, and ONE launch maps the weight gradients back.
+//
+// Replaces, per convolution and per step, the reference's weight-norm recomputation
+// (torch.nn.utils.weight_norm's forward pre-hook: w = g * v / ||v||, norm over every dim but 0 —
+// reference models.py:254, modules.py:128,135,145,191-206) and its autograd, plus the layout/precision
+// changes this implementation needs:
+//   forward  : w_fwd [k][c_out_p][c_in_p]  (tap-major, channels padded to the vector width)
+//              w_bwd [k][c_in_p][c_out_p]  with reversed taps (the data-gradient operand)
+//              in the compute dtype (bf16 or f32);
+//   backward : dv = (g/||v||) * (dW - v * <dW, v>/||v||^2),  dg = <dW, v>/||v||   (plain layers: dW re-laid-out)
+// One workgroup per weight-norm row (output channel of a Conv1d, INPUT channel of a ConvTranspose1d,
+// whose legacy weight_norm dim 0 is c_in).  ConvTranspose1d [c_in][c_out][k] is emitted as the 1x1
+// operand [1][k*c_out][c_in] that vits_convt_fold_cl expects.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+  return s;
+}
+
+__device__ __forceinline__ int find_entry(const vits_prep_entry* e, int n, int row) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (e[mid].row0 <= row) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+template <typename T> __device__ __forceinline__ void put(T* p, size_t i, float v);
+template <> __device__ __forceinline__ void put<float>(float* p, size_t i, float v) { p[i] = v; }
+template <> __device__ __forceinline__ void put<__bf16>(__bf16* p, size_t i, float v) { p[i] = (__bf16)v; }
+
+// element (row, inner) of the torch-layout parameter -> (tap, co, ci)
+struct Idx { int tap, co, ci; };
+__device__ __forceinline__ Idx locate(const vits_prep_entry& e, int r, int inner) {
+  Idx x;
+  if (e.layout == 0) {            // Conv1d [c_out][c_in][k]: row = co (within the entry), inner = ci*k + tap
+    x.co = r; x.ci = inner / e.k; x.tap = inner % e.k;
+  } else {                        // ConvTranspose1d [c_in][c_out][k]: row = ci, inner = co*k + j
+    x.ci = r; x.co = inner / e.k; x.tap = inner % e.k;
+  }
+  return x;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void prep_fwd(const vits_prep_entry* __restrict__ ents, int n_ents, T* __restrict__ w_fwd,
+                                                T* __restrict__ w_bwd) {
+  __shared__ float red[4];
+  const vits_prep_entry e = ents[find_entry(ents, n_ents, blockIdx.x)];
+  const int r = blockIdx.x - e.row0;                         // row within the entry
+  const int inner = (e.layout == 0) ? e.c_in * e.k : e.c_out * e.k;
+  const float* v = e.v + ((size_t)(e.row_lo + r)) * inner;
+  float scale = 1.f;
+  if (e.g) {
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < inner; i += blockDim.x) { const float a = v[i]; ss += a * a; }
+    ss = block_sum(ss, red);
+    scale = e.g[e.row_lo + r] / sqrtf(ss);
+  }
+  for (int i = threadIdx.x; i < inner; i += blockDim.x) {
+    const Idx x = locate(e, r, i);
+    const float val = v[i] * scale;
+    if (e.layout == 0) {
+      put<T>(w_fwd, e.off + ((size_t)x.tap * e.c_out_p + x.co) * e.c_in_p + x.ci, val);
+      put<T>(w_bwd, e.off + ((size_t)(e.k - 1 - x.tap) * e.c_in_p + x.ci) * e.c_out_p + x.co, val);
+    } else {
+      const size_t col = (size_t)x.tap * e.c_out + x.co;                   // column of the 1x1 operand
+      put<T>(w_fwd, e.off + col * e.c_in_p + x.ci, val);                   // [1][k*c_out][c_in_p]
+      put<T>(w_bwd, e.off + (size_t)x.ci * ((size_t)e.k * e.c_out) + col, val);   // [1][c_in][k*c_out]
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void prep_bwd(const vits_prep_entry* __restrict__ ents, int n_ents,
+                                                const float* __restrict__ dw, float* __restrict__ dparam) {
+  __shared__ float red[4];
+  const vits_prep_entry e = ents[find_entry(ents, n_ents, blockIdx.x)];
+  const int r = blockIdx.x - e.row0;
+  const int inner = (e.layout == 0) ? e.c_in * e.k : e.c_out * e.k;
+  const float* v = e.v + ((size_t)(e.row_lo + r)) * inner;
+  float* dv = dparam + e.off_dv + ((size_t)(e.row_lo + r)) * inner;
+  auto dw_at = [&](int i) -> float {
+    const Idx x = locate(e, r, i);
+    if (e.layout == 0) return dw[e.off + ((size_t)x.tap * e.c_out_p + x.co) * e.c_in_p + x.ci];
+    return dw[e.off + ((size_t)x.tap * e.c_out + x.co) * e.c_in_p + x.ci];
+  };
+  if (!e.g) {
+    for (int i = threadIdx.x; i < inner; i += blockDim.x) dv[i] = dw_at(i);
+    return;
+  }
+  float ss = 0.f, dot = 0.f;
+  for (int i = threadIdx.x; i < inner; i += blockDim.x) { const float a = v[i]; ss += a * a; dot += a * dw_at(i); }
+  ss = block_sum(ss, red);
+  dot = block_sum(dot, red);
+  const float norm = sqrtf(ss), gval = e.g[e.row_lo + r];
+  const float s = gval / norm, c = dot / ss;
+  for (int i = threadIdx.x; i < inner; i += blockDim.x) dv[i] = s * (dw_at(i) - v[i] * c);
+  if (threadIdx.x == 0) dparam[e.off_dg + e.row_lo + r] = dot / norm;
+}
+
+}  // namespace
+
+extern "C" int vits_weight_prep(const vits_prep_entry* entries, int n_entries, int total_rows, int dtype, void* w_fwd,
+                                void* w_bwd, void* stream) {
+  if (!entries || n_entries <= 0 || total_rows <= 0 || !w_fwd || !w_bwd) return VITS_E_BADARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == VITS_DT_BF16)
+    hipLaunchKernelGGL(prep_fwd<__bf16>, dim3(total_rows), dim3(256), 0, s, entries, n_entries, static_cast<__bf16*>(w_fwd), static_cast<__bf16*>(w_bwd));
+  else if (dtype == VITS_DT_F32)
+    hipLaunchKernelGGL(prep_fwd<float>, dim3(total_rows), dim3(256), 0, s, entries, n_entries, static_cast<float*>(w_fwd), static_cast<float*>(w_bwd));
+  else
+    return VITS_E_UNSUPPORTED;
+  return vits::check_launch("vits_weight_prep");
+}
+
+extern "C" int vits_weight_prep_bwd(const vits_prep_entry* entries, int n_entries, int total_rows, const float* dw,
+                                    float* dparam, void* stream) {
+  if (!entries || n_entries <= 0 || total_rows <= 0 || !dw || !dparam) return VITS_E_BADARG;
+  hipLaunchKernelGGL(prep_bwd, dim3(total_rows), dim3(256), 0, static_cast<hipStream_t>(stream), entries, n_entries, dw, dparam);
+  return vits::check_launch("vits_weight_prep_bwd");
+}

@@ -21,6 +21,7 @@ import torch
 
 from . import _lib
 from . import kernels as K
+from . import weight_arena as WA
 
 
 def convt_fold(p, bias, c_out, k, u, pad):
@@ -61,21 +62,34 @@ class DecoderPlan:
 
 
 def prepared_weights(gen):
-    """Parameters -> kernel-layout fp32 tensors (autograd-connected):  conv [c_out,c_in,k] ->
-    [k][c_out][c_in];  conv-transpose [c_in,c_out,k] -> [1][k*c_out][c_in];  conv_post padded to 8
-    output channels (vector width of the kernels)."""
-    out = [gen.conv_pre.weight.permute(2, 0, 1).contiguous(), gen.conv_pre.bias]
+    """Weights in DecoderFn's consumption order.  Inside a weight_arena.scope these are the arena's
+    handles; otherwise fp32 kernel-layout tensors prepared with torch ops (autograd-connected):
+    conv [c_out,c_in,k] -> [k][c_out][c_in];  conv-transpose [c_in,c_out,k] -> [1][k*c_out][c_in];
+    conv_post padded to 8 output channels (vector width of the kernels)."""
+    def conv(m):
+        h = WA.handle_for(m)
+        return h if h is not None else m.weight.permute(2, 0, 1).contiguous()
+
+    def convt(m):
+        h = WA.handle_for(m)
+        if h is not None:
+            return h
+        return m.weight.permute(2, 1, 0).reshape(1, m.kernel_size * m.out_channels, m.in_channels).contiguous()
+
+    out = [conv(gen.conv_pre), gen.conv_pre.bias]
     for i, up in enumerate(gen.ups):                               # consumption order of DecoderFn.forward
-        w = up.weight                                             # weight-normed [c_in, c_out, k]
-        out += [w.permute(2, 1, 0).reshape(1, up.kernel_size * up.out_channels, up.in_channels).contiguous(), up.bias]
+        out += [convt(up), up.bias]
         for rb in gen.resblocks[i * gen.num_kernels:(i + 1) * gen.num_kernels]:
             pairs = zip(rb.convs1, rb.convs2) if hasattr(rb, "convs1") else [(c,) for c in rb.convs]
             for group in pairs:
                 for c in group:
-                    out += [c.weight.permute(2, 0, 1).contiguous(), c.bias]
-    wp = gen.conv_post.weight                                      # [1, c, 7]
-    wp = torch.cat([wp, wp.new_zeros(7, wp.size(1), wp.size(2))], 0)
-    out.append(wp.permute(2, 0, 1).contiguous())
+                    out += [conv(c), c.bias]
+    h = WA.handle_for(gen.conv_post)
+    if h is None:
+        wp = gen.conv_post.weight                                  # [1, c, 7]
+        wp = torch.cat([wp, wp.new_zeros(7, wp.size(1), wp.size(2))], 0)
+        h = wp.permute(2, 0, 1).contiguous()
+    out.append(h)
     return out
 
 
@@ -85,7 +99,8 @@ class DecoderFn(torch.autograd.Function):
         """z [b, t, c] channels-last (any float dtype), cond float32 [b, c_up0] or None, wb from
         prepared_weights().  Returns y [b, t*prod(u), 8] in `dtype` (channel 0 is the waveform)."""
         C = K.conv1d_cl_raw
-        w = [t.detach().to(dtype) if t.dim() == 3 else t.detach().float() for t in wb]     # weights in compute dtype, biases fp32
+        R = [WA.resolve(t, dtype) if t.dim() == 3 else None for t in wb]
+        w = [r.fwd if r is not None else t.detach().float() for r, t in zip(R, wb)]        # weights in compute dtype, biases fp32
         it = iter(range(len(w)))
         saved = []
         z = z.detach().to(dtype).contiguous()
@@ -137,17 +152,23 @@ class DecoderFn(torch.autograd.Function):
         saved += [h, y]
         ctx.plan, ctx.dtype, ctx.idx, ctx.i_post = plan, dtype, idx, i_post
         ctx.has_cond = cond is not None
-        ctx.n_saved = len(saved)
-        ctx.save_for_backward(*saved, *w)
+        ctx.R = R
+        ctx.save_for_backward(*saved)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         plan, dtype, idx = ctx.plan, ctx.dtype, ctx.idx
         C, WG = K.conv1d_cl_raw, K.conv1d_cl_wgrad_raw
-        saved = list(ctx.saved_tensors[: ctx.n_saved])
-        w = list(ctx.saved_tensors[ctx.n_saved:])
-        grads = [None] * len(w)
+        saved = list(ctx.saved_tensors)
+        R = ctx.R
+        grads = [None] * len(R)
+
+        def flip_t(r):                       # data-gradient operand of weight slot r
+            return WA.bwd_operand(R[r])
+
+        def WGo(x, dy, k, slot, **kw):       # weight gradient written into the arena's dw region when there is one
+            return WG(x, dy, k, out=R[slot].dw, **kw)
 
         def bias_grad(d):
             return d.sum((0, 1), dtype=torch.float32)
@@ -155,8 +176,8 @@ class DecoderFn(torch.autograd.Function):
         y = saved.pop()
         h = saved.pop()
         dpre = (dy.to(torch.float32) * (1.0 - y.float() ** 2)).to(dtype).contiguous()      # tanh'
-        grads[ctx.i_post] = WG(h, dpre, 7, pad=3, in_slope=0.01)
-        dh = C(dpre, flip_t(w[ctx.i_post]), None, mg_src=h, pad=3, mg_slope=0.01)
+        grads[ctx.i_post] = WGo(h, dpre, 7, ctx.i_post, pad=3, in_slope=0.01)
+        dh = C(dpre, flip_t(ctx.i_post), None, mg_src=h, pad=3, mg_slope=0.01)
 
         ri = len(plan.res)
         for s in reversed(range(len(plan.ups))):
@@ -175,44 +196,44 @@ class DecoderFn(torch.autograd.Function):
                         t1 = saved.pop()
                         r_in = saved.pop()
                         p2, p1 = (rk - 1) // 2, (rk * d - d) // 2
-                        grads[i2[0]] = WG(t1, dr, rk, pad=p2, in_slope=0.1)
+                        grads[i2[0]] = WGo(t1, dr, rk, i2[0], pad=p2, in_slope=0.1)
                         grads[i2[1]] = bias_grad(dr)
-                        dt1 = C(dr, flip_t(w[i2[0]]), None, mg_src=t1, pad=p2, mg_slope=0.1)
-                        grads[i1[0]] = WG(r_in, dt1, rk, dil=d, pad=p1, in_slope=0.1)
+                        dt1 = C(dr, flip_t(i2[0]), None, mg_src=t1, pad=p2, mg_slope=0.1)
+                        grads[i1[0]] = WGo(r_in, dt1, rk, i1[0], dil=d, pad=p1, in_slope=0.1)
                         grads[i1[1]] = bias_grad(dt1)
                         if first:     # gradient wrt the stage input x: accumulated over the parallel resblocks
-                            _dgrad_res(dt1, w[i1[0]], r_in, dr, d, p1, out=dx, accum=j < plan.num_kernels - 1)
+                            _dgrad_res(dt1, flip_t(i1[0]), r_in, dr, d, p1, out=dx, accum=j < plan.num_kernels - 1)
                             dr = None
                         else:
-                            dr = _dgrad_res(dt1, w[i1[0]], r_in, dr, d, p1)
+                            dr = _dgrad_res(dt1, flip_t(i1[0]), r_in, dr, d, p1)
                     else:
                         r_in = saved.pop()
                         p1 = (rk * d - d) // 2
-                        grads[i1[0]] = WG(r_in, dr, rk, dil=d, pad=p1, in_slope=0.1)
+                        grads[i1[0]] = WGo(r_in, dr, rk, i1[0], dil=d, pad=p1, in_slope=0.1)
                         grads[i1[1]] = bias_grad(dr)
                         if first:
-                            _dgrad_res(dr, w[i1[0]], r_in, dr, d, p1, out=dx, accum=j < plan.num_kernels - 1)
+                            _dgrad_res(dr, flip_t(i1[0]), r_in, dr, d, p1, out=dx, accum=j < plan.num_kernels - 1)
                             dr = None
                         else:
-                            dr = _dgrad_res(dr, w[i1[0]], r_in, dr, d, p1)
+                            dr = _dgrad_res(dr, flip_t(i1[0]), r_in, dr, d, p1)
             # upsampler: x = fold(conv1x1(lrelu(h_prev)))
             h_prev = saved.pop()
             iu = idx["ups"][s]
             grads[iu[1]] = bias_grad(dx)
             dp = convt_unfold(dx, h_prev.size(1), k, u, pad)
-            grads[iu[0]] = WG(h_prev, dp, 1, in_slope=0.1)
-            dh = C(dp, flip_t(w[iu[0]]), None, mg_src=h_prev, mg_slope=0.1)
+            grads[iu[0]] = WGo(h_prev, dp, 1, iu[0], in_slope=0.1)
+            dh = C(dp, flip_t(iu[0]), None, mg_src=h_prev, mg_slope=0.1)
         z = saved.pop()
         i_pre = idx["pre"]
-        grads[i_pre[0]] = WG(z, dh, 7, pad=3)
+        grads[i_pre[0]] = WGo(z, dh, 7, i_pre[0], pad=3)
         grads[i_pre[1]] = bias_grad(dh)
-        dz = C(dh, flip_t(w[i_pre[0]]), None, pad=3)
+        dz = C(dh, flip_t(i_pre[0]), None, pad=3)
         dcond = dh.sum(1, dtype=torch.float32) if ctx.has_cond else None
         return (None, None, dz, dcond, *grads)
 
 
-def _dgrad_res(dy, w, x_in, skip, dil, pad, out=None, accum=False):
+def _dgrad_res(dy, w_t, x_in, skip, dil, pad, out=None, accum=False):
     """d/dx of  conv(lrelu_0.1(x)) + x  given the output gradient:  conv^T(dy) * lrelu'(x) + skip,
     one kernel (RES_AFTER adds the skip term after the activation-derivative multiplier)."""
-    return K.conv1d_cl_raw(dy, flip_t(w), None, res=skip, mg_src=x_in, out=out, dil=dil, pad=pad, mg_slope=0.1,
+    return K.conv1d_cl_raw(dy, w_t, None, res=skip, mg_src=x_in, out=out, dil=dil, pad=pad, mg_slope=0.1,
                            flags=K.CONV_RES_AFTER | (K.CONV_ACCUM if accum else 0))

@@ -26,67 +26,71 @@ def broadcast_parameters(module, src=0):
 
 
 class GradBuckets:
-    """Flat gradient storage + overlapped all-reduce for one network."""
+    """Flat gradient buckets + overlapped all-reduce for one network.
+
+    Gradients are produced by autograd as it likes (param.grad starts each step as None, so the
+    engine installs the incoming tensor without an extra add kernel per parameter — ~1000 launches
+    per step for this model).  A post-accumulate-grad hook counts a bucket's parameters; when the
+    last one has arrived the bucket's gradients are packed into its flat buffer by ONE multi-tensor
+    copy, param.grad is re-pointed at the flat views, and the bucket's all-reduce starts on the
+    communication stream while backward continues.  With a single process there is nothing to
+    exchange and the buckets are never packed."""
 
     def __init__(self, params, bucket_bytes=64 << 20, group=None):
         self.params = [p for p in params if p.requires_grad]
         self.group = group
         self.world = world()
-        # buckets are filled in reverse registration order ~ the order backward produces gradients
-        self.buckets = []          # (flat tensor, [params])
+        self.buckets = []          # (flat tensor, [params], [views])
         self._bucket_of = {}
-        cur, cur_bytes = [], 0
-        for p in reversed(self.params):
-            nbytes = p.numel() * p.element_size()
-            if cur and (cur_bytes + nbytes > bucket_bytes or p.dtype != cur[0].dtype):
+        if self.world > 1:
+            cur, cur_bytes = [], 0
+            for p in reversed(self.params):      # reverse registration order ~ order backward produces gradients
+                nbytes = p.numel() * p.element_size()
+                if cur and (cur_bytes + nbytes > bucket_bytes or p.dtype != cur[0].dtype):
+                    self._close(cur)
+                    cur, cur_bytes = [], 0
+                cur.append(p)
+                cur_bytes += nbytes
+            if cur:
                 self._close(cur)
-                cur, cur_bytes = [], 0
-            cur.append(p)
-            cur_bytes += nbytes
-        if cur:
-            self._close(cur)
+            self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         self._pending = [0] * len(self.buckets)
         self._work = []
         self._launched = [False] * len(self.buckets)
         self._enabled = True
-        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 
     def _close(self, plist):
         n = sum(p.numel() for p in plist)
         flat = torch.zeros(n, dtype=plist[0].dtype, device=plist[0].device)
-        off = 0
+        views, off = [], 0
         for p in plist:
-            p.grad = flat[off:off + p.numel()].view_as(p)
+            views.append(flat[off:off + p.numel()].view_as(p))
             off += p.numel()
             self._bucket_of[p] = len(self.buckets)
-        self.buckets.append((flat, plist))
+        self.buckets.append((flat, plist, views))
 
     def zero_grad(self):
-        """One memset per bucket (replaces optimizer.zero_grad(); grads stay views of the buckets)."""
-        for i, (flat, plist) in enumerate(self.buckets):
-            flat.zero_()
+        """Replaces optimizer.zero_grad(): drop the gradients (set_to_none) and re-arm the buckets."""
+        for p in self.params:
+            p.grad = None
+        for i, (_, plist, _) in enumerate(self.buckets):
             self._pending[i] = len(plist)
             self._launched[i] = False
-            for p in plist:                      # autograd may have replaced .grad (e.g. set_to_none)
-                if p.grad is None or p.grad.data_ptr() < flat.data_ptr() or p.grad.data_ptr() >= flat.data_ptr() + flat.numel() * flat.element_size():
-                    self._rebind(i)
-                    break
         self._work = []
-
-    def _rebind(self, i):
-        flat, plist = self.buckets[i]
-        off = 0
-        for p in plist:
-            p.grad = flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
 
     def _launch(self, i):
         if self._launched[i]:
             return
         self._launched[i] = True
-        if self.world == 1:
-            return
-        flat = self.buckets[i][0]
+        flat, plist, views = self.buckets[i]
+        have = [(v, p.grad) for v, p in zip(views, plist) if p.grad is not None]
+        missing = [v for v, p in zip(views, plist) if p.grad is None]
+        if missing:
+            torch._foreach_zero_(missing)
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        for v, p in zip(views, plist):
+            p.grad = v
         if dist.get_backend(self.group) == "nccl":
             self._work.append(dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
         else:

@@ -187,10 +187,9 @@ class PosteriorEncoder(nn.Module):
         cin = self.in_channels
         cpad = (-cin) % 8
         x_cl = torch.nn.functional.pad(x.transpose(1, 2), (0, cpad)).to(dtype).contiguous()
-        w_pre = torch.nn.functional.pad(self.pre.weight, (0, 0, 0, cpad))
-        h = wn_cl.conv_cl(x_cl, wn_cl.prep_conv(w_pre), self.pre.bias, lengths, mask_out=True)
+        h = wn_cl.conv_cl(x_cl, wn_cl.weight_of(self.pre, pad_in=cpad), self.pre.bias, lengths, mask_out=True)
         h = wn_cl.wn_forward_cl(self.enc, h, lengths, g)
-        stats = wn_cl.conv_cl(h, wn_cl.prep_conv(self.proj.weight), self.proj.bias, lengths, mask_out=True).float()
+        stats = wn_cl.conv_cl(h, wn_cl.weight_of(self.proj), self.proj.bias, lengths, mask_out=True).float()
         m, logs = stats[..., :self.out_channels], stats[..., self.out_channels:]
         z = (m + noise.randn_like(m.transpose(1, 2)).transpose(1, 2) * torch.exp(logs)) * x_mask.transpose(1, 2)
         return z.transpose(1, 2), m.transpose(1, 2), logs.transpose(1, 2), x_mask
@@ -381,7 +380,54 @@ class SynthesizerTrn(nn.Module):
         neg_cent4 = torch.sum(-0.5 * (m_p ** 2) * s_p_sq_r, [1], keepdim=True)         # [b, 1, t_s]
         return neg_cent1 + neg_cent2 + neg_cent3 + neg_cent4
 
+    @staticmethod
+    def _arena_specs(net):
+        """Every convolution of the posterior encoder, the flow and the decoder that runs on the HIP
+        kernels, for weight_arena (one preparation launch per forward, one gradient launch per backward)."""
+        from .weight_arena import Spec
+
+        def wn_specs(wn):
+            H, out = wn.hidden_channels, []
+            for i in range(wn.n_layers):
+                out.append(Spec(wn.in_layers[i]))
+                rs = wn.res_skip_layers[i]
+                if i < wn.n_layers - 1:
+                    out += [Spec(rs, "res", 0, H), Spec(rs, "skip", H, H)]
+                else:
+                    out.append(Spec(rs, "skip"))
+            return out
+
+        specs = [Spec(net.enc_q.pre, c_in_p=(net.enc_q.in_channels + 7) // 8 * 8)] + wn_specs(net.enc_q.enc) + [Spec(net.enc_q.proj)]
+        for fl in net.flow.flows:
+            if isinstance(fl, modules.ResidualCouplingLayer):
+                specs += [Spec(fl.pre)] + wn_specs(fl.enc) + [Spec(fl.post)]
+        dec = net.dec
+        specs.append(Spec(dec.conv_pre))
+        for i, up in enumerate(dec.ups):
+            specs.append(Spec(up, transpose=True))
+            for rb in dec.resblocks[i * dec.num_kernels:(i + 1) * dec.num_kernels]:
+                for c in (list(rb.convs1) + list(rb.convs2)) if hasattr(rb, "convs1") else list(rb.convs):
+                    specs.append(Spec(c))
+        specs.append(Spec(dec.conv_post, c_out_p=8))
+        return specs
+
+    def _scope(self):
+        from . import weight_arena
+        return weight_arena.scope(self, SynthesizerTrn._arena_specs)
+
     def forward(self, x, x_lengths, y, y_lengths, sid=None):
+        with self._scope():
+            return self._forward(x, x_lengths, y, y_lengths, sid)
+
+    def infer(self, x, x_lengths, sid=None, noise_scale=1, length_scale=1, noise_scale_w=1.0, max_len=None):
+        with self._scope():
+            return self._infer(x, x_lengths, sid, noise_scale, length_scale, noise_scale_w, max_len)
+
+    def voice_conversion(self, y, y_lengths, sid_src, sid_tgt):
+        with self._scope():
+            return self._voice_conversion(y, y_lengths, sid_src, sid_tgt)
+
+    def _forward(self, x, x_lengths, y, y_lengths, sid=None):
         x, m_p, logs_p, x_mask = self.enc_p(x, x_lengths)
         g = self._speaker(sid)
         z, m_q, logs_q, y_mask = self.enc_q(y, y_lengths, g=g)
@@ -409,7 +455,7 @@ class SynthesizerTrn(nn.Module):
         o = self.dec(z_slice, g=g)
         return o, l_length, attn, ids_slice, x_mask, y_mask, (z, z_p, m_p, logs_p, m_q, logs_q)
 
-    def infer(self, x, x_lengths, sid=None, noise_scale=1, length_scale=1, noise_scale_w=1.0, max_len=None):
+    def _infer(self, x, x_lengths, sid=None, noise_scale=1, length_scale=1, noise_scale_w=1.0, max_len=None):
         x, m_p, logs_p, x_mask = self.enc_p(x, x_lengths)
         g = self._speaker(sid)
         if self.use_sdp:
@@ -431,7 +477,7 @@ class SynthesizerTrn(nn.Module):
         o = self.dec((z * y_mask)[:, :, :max_len], g=g)
         return o, attn, y_mask, (z, z_p, m_p, logs_p)
 
-    def voice_conversion(self, y, y_lengths, sid_src, sid_tgt):
+    def _voice_conversion(self, y, y_lengths, sid_src, sid_tgt):
         assert self.n_speakers > 0, "n_speakers have to be larger than 0."
         g_src = self.emb_g(sid_src).unsqueeze(-1)
         g_tgt = self.emb_g(sid_tgt).unsqueeze(-1)

@@ -272,9 +272,9 @@ class ResidualCouplingLayer(nn.Module):
             lengths = mask_cl[:, :, 0].sum(-1).to(torch.int32)
         half = self.half_channels
         x0, x1 = x[..., :half], x[..., half:]
-        h = wn_cl.conv_cl(x0, wn_cl.prep_conv(self.pre.weight), self.pre.bias, lengths, mask_out=True)
+        h = wn_cl.conv_cl(x0, wn_cl.weight_of(self.pre), self.pre.bias, lengths, mask_out=True)
         h = wn_cl.wn_forward_cl(self.enc, h, lengths, g)
-        stats = wn_cl.conv_cl(h, wn_cl.prep_conv(self.post.weight), self.post.bias, lengths, mask_out=True).to(x.dtype)
+        stats = wn_cl.conv_cl(h, wn_cl.weight_of(self.post), self.post.bias, lengths, mask_out=True).to(x.dtype)
         if not self.mean_only:
             m, logs = stats[..., :half], stats[..., half:]
         else:

@@ -1,0 +1,179 @@
+"""Weight arena: the fp32 master parameters of a whole group of convolutions are turned into the HIP
+kernels' operands by ONE launch per forward (csrc/weight_prep.hip: weight-norm, tap-major layout,
+padding, compute dtype, plus the tap-reversed transposed copy the data-gradient calls need), and
+their weight gradients are mapped back to parameter gradients by ONE launch per backward.
+
+Autograd sees one node (`PrepFn`) whose outputs are fp32 *handles*, one per convolution (slice); the
+fused layer nodes (decoder_cl.DecoderFn, wn_cl.WNFn, wn_cl.ConvCLFn) take a handle as their weight
+input, resolve it here to the low-precision operands, write their fp32 weight gradient straight
+into the arena's `dw` region and return that view as the handle's gradient — so nothing is copied
+and the parameter gradients (weight_v, weight_g, weight) come out of a single kernel.
+
+Scope: `with weight_arena.scope(synthesizer): ...` prepares every registered convolution of the
+generator's posterior encoder, flow and decoder; outside a scope the layer nodes fall back to
+per-layer torch preparation (same numerics, many more launches).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+_DT = {torch.float32: 0, torch.bfloat16: 2}
+_current = None            # dict (id(module), part) -> handle tensor, valid inside a scope
+_registry = {}             # handle.data_ptr() -> (arena, index)
+
+
+class Spec:
+    def __init__(self, module, part=None, row_lo=0, n_rows=None, c_out_p=None, c_in_p=None, transpose=False):
+        self.module, self.part, self.transpose = module, part, transpose
+        has_g = hasattr(module, "weight_g")
+        self.v = module.weight_v if has_g else module.weight
+        self.g = module.weight_g if has_g else None
+        d0, d1, k = self.v.shape
+        self.k = k
+        if transpose:                         # ConvTranspose1d [c_in][c_out][k], rows = input channels
+            self.c_in, self.c_out = d0, d1
+            self.row_lo, self.n_rows = 0, d0
+            self.c_in_p, self.c_out_p = c_in_p or d0, d1
+            self.numel = k * d1 * self.c_in_p
+            self.fwd_shape, self.bwd_shape = (1, k * d1, self.c_in_p), (1, self.c_in_p, k * d1)
+        else:                                 # Conv1d [c_out][c_in][k], rows = output channels
+            self.c_in = d1
+            self.row_lo = row_lo
+            self.n_rows = self.c_out = (d0 - row_lo) if n_rows is None else n_rows
+            self.c_out_p, self.c_in_p = c_out_p or self.c_out, c_in_p or d1
+            self.numel = k * self.c_out_p * self.c_in_p
+            self.fwd_shape, self.bwd_shape = (k, self.c_out_p, self.c_in_p), (k, self.c_in_p, self.c_out_p)
+
+
+class WeightArena:
+    def __init__(self, specs, dtype):
+        self.specs, self.dtype = specs, dtype
+        dev = specs[0].v.device
+        self.params, pidx = [], {}
+        for s in specs:
+            for p in (s.v, s.g):
+                if p is not None and id(p) not in pidx:
+                    pidx[id(p)] = len(self.params)
+                    self.params.append(p)
+        # parameter-gradient arena: one region per parameter, torch layout
+        self.p_off, off = [], 0
+        for p in self.params:
+            self.p_off.append(off)
+            off += p.numel()
+        self.dparam = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.dparam_views = [self.dparam[o:o + p.numel()].view_as(p) for o, p in zip(self.p_off, self.params)]
+        # operand arenas
+        offs, off, row0 = [], 0, 0
+        ents = (_lib.PrepEntry * len(specs))()
+        for i, s in enumerate(specs):
+            offs.append(off)
+            e = ents[i]
+            e.v, e.g = s.v.data_ptr(), (s.g.data_ptr() if s.g is not None else None)
+            e.off, e.off_dv = off, self.p_off[pidx[id(s.v)]]
+            e.off_dg = self.p_off[pidx[id(s.g)]] if s.g is not None else 0
+            e.layout, e.c_out, e.c_in, e.k = (1 if s.transpose else 0), s.c_out, s.c_in, s.k
+            e.c_out_p, e.c_in_p, e.row_lo, e.n_rows, e.row0 = s.c_out_p, s.c_in_p, s.row_lo, s.n_rows, row0
+            row0 += s.n_rows
+            off += (s.numel + 63) & ~63                         # keep every operand 128-byte aligned
+        self.total_rows, self.n = row0, len(specs)
+        self.table = torch.frombuffer(bytearray(bytes(ents)), dtype=torch.uint8).to(dev)
+        self.w_fwd = torch.zeros(off, dtype=dtype, device=dev)
+        self.w_bwd = torch.zeros(off, dtype=dtype, device=dev)
+        self.handle = self.w_fwd if dtype == torch.float32 else torch.empty(off, dtype=torch.float32, device=dev)
+        self.dw = torch.zeros(off, dtype=torch.float32, device=dev)
+        view = lambda buf, o, s, shape: buf[o:o + s.numel].view(shape)
+        self.fwd = [view(self.w_fwd, o, s, s.fwd_shape) for o, s in zip(offs, specs)]
+        self.bwd = [view(self.w_bwd, o, s, s.bwd_shape) for o, s in zip(offs, specs)]
+        self.handles = [view(self.handle, o, s, s.fwd_shape) for o, s in zip(offs, specs)]
+        self.dws = [view(self.dw, o, s, s.fwd_shape) for o, s in zip(offs, specs)]
+        self.ptrs = [p.data_ptr() for p in self.params]
+        for i, h in enumerate(self.handles):
+            _registry[h.data_ptr()] = (self, i)
+
+    def stale(self):
+        return any(p.data_ptr() != q for p, q in zip(self.params, self.ptrs))
+
+    def prepare(self):
+        return PrepFn.apply(self, *self.params)
+
+
+class PrepFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, arena, *params):
+        rc = _lib.lib().vits_weight_prep(arena.table.data_ptr(), arena.n, arena.total_rows, _DT[arena.dtype],
+                                         arena.w_fwd.data_ptr(), arena.w_bwd.data_ptr(), _lib.stream_ptr())
+        _lib.check(rc, "vits_weight_prep")
+        ctx.arena = arena
+        return tuple(h.detach() for h in arena.handles)
+
+    @staticmethod
+    def backward(ctx, *dws):
+        arena = ctx.arena
+        for i, d in enumerate(dws):
+            if d is None:
+                arena.dws[i].zero_()
+            elif d.data_ptr() != arena.dws[i].data_ptr():
+                arena.dws[i].copy_(d)
+        rc = _lib.lib().vits_weight_prep_bwd(arena.table.data_ptr(), arena.n, arena.total_rows, arena.dw.data_ptr(),
+                                             arena.dparam.data_ptr(), _lib.stream_ptr())
+        _lib.check(rc, "vits_weight_prep_bwd")
+        return (None, *arena.dparam_views)
+
+
+class Resolved:
+    """What a layer node needs for one convolution weight."""
+    __slots__ = ("fwd", "bwd", "dw")
+
+    def __init__(self, fwd, bwd, dw):
+        self.fwd, self.bwd, self.dw = fwd, bwd, dw
+
+
+def resolve(w, dtype):
+    """w: a handle from an arena, or any fp32 kernel-layout weight [k][c_out][c_in] (fallback)."""
+    hit = _registry.get(w.data_ptr())
+    if hit is not None and hit[0].dtype == dtype and tuple(w.shape) == tuple(hit[0].handles[hit[1]].shape):
+        a, i = hit
+        return Resolved(a.fwd[i], a.bwd[i], a.dws[i])
+    wd = w.detach().to(dtype)
+    return Resolved(wd, None, None)
+
+
+def bwd_operand(res):
+    """Tap-reversed transposed operand for the data-gradient call."""
+    if res.bwd is not None:
+        return res.bwd
+    return res.fwd.flip(0).transpose(1, 2).contiguous()
+
+
+def handle_for(module, part=None):
+    """Inside a scope: the prepared handle of `module` (or of one of its row slices); else None."""
+    if _current is None:
+        return None
+    return _current.get((id(module), part))
+
+
+class scope:
+    """Prepare all registered convolutions of `root` for the duration of a forward pass."""
+
+    def __init__(self, root, collect):
+        self.root, self.collect = root, collect
+
+    def __enter__(self):
+        global _current
+        dtype = torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
+        cache = self.root.__dict__.setdefault("_weight_arenas", {})
+        arena = cache.get(dtype)
+        if arena is None or arena.stale():
+            arena = WeightArena(self.collect(self.root), dtype)
+            cache[dtype] = arena
+        handles = arena.prepare()
+        self.prev = _current
+        _current = {(id(s.module), s.part): h for s, h in zip(arena.specs, handles)}
+        return arena
+
+    def __exit__(self, *exc):
+        global _current
+        _current = self.prev
+        return False

@@ -15,6 +15,7 @@ import torch
 
 from . import _lib
 from . import kernels as K
+from . import weight_arena as WA
 
 
 def flip_t(w):
@@ -38,37 +39,40 @@ def prep_conv(weight):
 
 class ConvCLFn(torch.autograd.Function):
     """y = mask_out( conv(lrelu_slope(mask_in(x)), w) + bias ), x [b,t,c_in] channels-last (may be a channel
-    slice), w [k][c_out][c_in] fp32 kernel layout.  Data and weight gradients by the same HIP kernels."""
+    slice), w: arena handle or fp32 kernel-layout weight [k][c_out][c_in].  Data and weight gradients by
+    the same HIP kernels."""
 
     @staticmethod
     def forward(ctx, dtype, x, w, bias, lengths, dil, pad, in_slope, mask_in, mask_out):
         xd = x.detach()
         if xd.dtype != dtype:
             xd = xd.to(dtype)
-        wd = w.detach().to(dtype)
+        R = WA.resolve(w, dtype)
         flags = (K.CONV_MASK_IN if mask_in else 0) | (K.CONV_MASK_OUT if mask_out else 0)
-        y = K.conv1d_cl_raw(xd, wd, None if bias is None else bias.detach().float(), lengths=lengths, dil=dil, pad=pad,
+        y = K.conv1d_cl_raw(xd, R.fwd, None if bias is None else bias.detach().float(), lengths=lengths, dil=dil, pad=pad,
                             in_slope=in_slope, flags=flags)
-        ctx.save_for_backward(xd, wd)
+        ctx.save_for_backward(xd)
+        ctx.R = R
         ctx.lengths, ctx.cfg, ctx.has_bias, ctx.x_dtype = lengths, (dil, pad, in_slope, mask_in, mask_out), bias is not None, x.dtype
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        xd, wd = ctx.saved_tensors
+        (xd,) = ctx.saved_tensors
+        R = ctx.R
         dil, pad, in_slope, mask_in, mask_out = ctx.cfg
-        k = wd.size(0)
+        k = R.fwd.size(0)
         dy = dy.contiguous()
         if mask_out:                                    # d(y * mask): zero rows first (one pass, reused three times)
             t = dy.size(1)
             dy = dy * (torch.arange(t, device=dy.device)[None, :, None] < ctx.lengths[:, None, None])
         dw = K.conv1d_cl_wgrad_raw(xd, dy, k, lengths=ctx.lengths, dil=dil, pad=pad, in_slope=in_slope,
-                                   flags=K.CONV_MASK_IN if mask_in else 0)
+                                   flags=K.CONV_MASK_IN if mask_in else 0, out=R.dw)
         db = dy.sum((0, 1), dtype=torch.float32) if ctx.has_bias else None
         dx = None
         if ctx.needs_input_grad[1]:
             xs = xd if xd.is_contiguous() else xd.contiguous()
-            dx = K.conv1d_cl_raw(dy, flip_t(wd), None, mg_src=xs if in_slope != 1.0 else None, lengths=ctx.lengths, dil=dil,
+            dx = K.conv1d_cl_raw(dy, WA.bwd_operand(R), None, mg_src=xs if in_slope != 1.0 else None, lengths=ctx.lengths, dil=dil,
                                  pad=dil * (k - 1) - pad, mg_slope=in_slope, flags=K.CONV_MASK_OUT if mask_in else 0)
             if dx.dtype != ctx.x_dtype:
                 dx = dx.to(ctx.x_dtype)
@@ -79,6 +83,18 @@ def conv_cl(x, w, bias=None, lengths=None, dil=1, pad=0, in_slope=1.0, mask_in=F
     return ConvCLFn.apply(dtype or compute_dtype(), x, w, bias, lengths, dil, pad, in_slope, mask_in, mask_out)
 
 
+def weight_of(module, part=None, pad_in=0):
+    """Kernel-layout weight of a conv module: the arena handle inside a weight_arena.scope, else the
+    torch-prepared fp32 tensor (optionally with zero-padded input channels)."""
+    h = WA.handle_for(module, part)
+    if h is not None:
+        return h
+    w = module.weight
+    if pad_in:
+        w = torch.nn.functional.pad(w, (0, 0, 0, pad_in))
+    return prep_conv(w)
+
+
 class WNPlan:
     def __init__(self, wn):
         self.H, self.k, self.L = wn.hidden_channels, wn.kernel_size[0], wn.n_layers
@@ -87,10 +103,19 @@ class WNPlan:
 
 
 def wn_prepared_weights(wn):
-    out = []
+    """Per layer: w_in, b_in, w_res (None for the last layer), w_skip, b_rs."""
+    H, out = wn.hidden_channels, []
     for i in range(wn.n_layers):
-        out += [prep_conv(wn.in_layers[i].weight), wn.in_layers[i].bias,
-                prep_conv(wn.res_skip_layers[i].weight), wn.res_skip_layers[i].bias]
+        rs = wn.res_skip_layers[i]
+        w_in = WA.handle_for(wn.in_layers[i])
+        if w_in is not None:
+            w_res = WA.handle_for(rs, "res") if i < wn.n_layers - 1 else None
+            w_skip = WA.handle_for(rs, "skip")
+        else:
+            w_in = prep_conv(wn.in_layers[i].weight)
+            w_rs = prep_conv(rs.weight)
+            w_res, w_skip = (w_rs[:, :H].contiguous(), w_rs[:, H:].contiguous()) if i < wn.n_layers - 1 else (None, w_rs)
+        out += [w_in, wn.in_layers[i].bias, w_res, w_skip, rs.bias]
     return out
 
 
@@ -105,41 +130,42 @@ def wn_cond(wn, g, n_items):
 class WNFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, plan, dtype, x, lengths, cond, *wb):
-        """x [b,t,H] channels-last with rows >= lengths already zero; cond [L][b][2H] fp32 or None."""
+        """x [b,t,H] channels-last with rows >= lengths already zero; cond [L][b][2H] fp32 or None;
+        wb from wn_prepared_weights()."""
         C = K.conv1d_cl_raw
         H, L, k = plan.H, plan.L, plan.k
-        w = [t.detach().to(dtype) if t.dim() == 3 else t.detach().float() for t in wb]
+        R = [WA.resolve(t, dtype) if (t is not None and t.dim() == 3) else None for t in wb]
+        bias = [t.detach().float() if (t is not None and t.dim() == 1) else None for t in wb]
         h = x.detach().to(dtype).contiguous()
         cd = None if cond is None else cond.detach().float().contiguous()
         out = torch.empty_like(h)
         saved = []
         for i in range(L):
-            w_in, b_in, w_rs, b_rs = w[4 * i: 4 * i + 4]
+            r_in, b_in, r_res, r_skip, b_rs = R[5 * i], bias[5 * i + 1], R[5 * i + 2], R[5 * i + 3], bias[5 * i + 4]
             d = plan.dils[i]
             pre = torch.empty(h.size(0), h.size(1), 2 * H, device=h.device, dtype=dtype)
-            acts = C(h, w_in, b_in, bias_b=None if cd is None else cd[i], dil=d, pad=(k * d - d) // 2,
+            acts = C(h, r_in.fwd, b_in, bias_b=None if cd is None else cd[i], dil=d, pad=(k * d - d) // 2,
                      flags=K.CONV_GATE, gate_h=H, out2=pre)
             acc = K.CONV_ACCUM if i > 0 else 0
             if i < L - 1:
-                h_next = C(acts, w_rs[:, :H], b_rs[:H], res=h, lengths=lengths, flags=K.CONV_MASK_OUT)
-                C(acts, w_rs[:, H:], b_rs[H:], out=out, lengths=lengths, flags=K.CONV_MASK_OUT | acc)
+                h_next = C(acts, r_res.fwd, b_rs[:H], res=h, lengths=lengths, flags=K.CONV_MASK_OUT)
+                C(acts, r_skip.fwd, b_rs[H:], out=out, lengths=lengths, flags=K.CONV_MASK_OUT | acc)
             else:
                 h_next = None
-                C(acts, w_rs, b_rs, out=out, lengths=lengths, flags=K.CONV_MASK_OUT | acc)
+                C(acts, r_skip.fwd, b_rs, out=out, lengths=lengths, flags=K.CONV_MASK_OUT | acc)
             saved += [h, pre, acts]
             h = h_next
-        ctx.plan, ctx.dtype, ctx.lengths, ctx.has_cond, ctx.n_saved = plan, dtype, lengths, cd is not None, len(saved)
-        ctx.save_for_backward(*saved, *w)
+        ctx.plan, ctx.dtype, ctx.lengths, ctx.has_cond, ctx.R = plan, dtype, lengths, cd is not None, R
+        ctx.save_for_backward(*saved)
         return out
 
     @staticmethod
     def backward(ctx, d_out):
-        plan, dtype, lengths = ctx.plan, ctx.dtype, ctx.lengths
+        plan, dtype, lengths, R = ctx.plan, ctx.dtype, ctx.lengths, ctx.R
         C, WG = K.conv1d_cl_raw, K.conv1d_cl_wgrad_raw
         H, L, k = plan.H, plan.L, plan.k
-        saved = list(ctx.saved_tensors[: ctx.n_saved])
-        w = list(ctx.saved_tensors[ctx.n_saved:])
-        grads = [None] * len(w)
+        saved = list(ctx.saved_tensors)
+        grads = [None] * len(R)
         t = d_out.size(1)
         rowmask = (torch.arange(t, device=d_out.device)[None, :, None] < lengths[:, None, None])
         d_o = (d_out * rowmask).to(dtype).contiguous()          # d(output * x_mask)
@@ -148,31 +174,28 @@ class WNFn(torch.autograd.Function):
         d_h = None
         for i in reversed(range(L)):
             acts, pre, h = saved.pop(), saved.pop(), saved.pop()
-            w_in, b_in, w_rs, b_rs = w[4 * i: 4 * i + 4]
+            r_in, r_res, r_skip = R[5 * i], R[5 * i + 2], R[5 * i + 3]
             d = plan.dils[i]
             pad = (k * d - d) // 2
+            grads[5 * i + 3] = WG(acts, d_o, 1, out=r_skip.dw)
             if i == L - 1:
-                grads[4 * i + 2] = WG(acts, d_o, 1)
-                grads[4 * i + 3] = s_o
-                d_pre = C(d_o, flip_t(w_rs), None, mg_src=pre, lengths=lengths, flags=K.CONV_GATE_BWD | K.CONV_MASK_OUT, gate_h=H)
+                grads[5 * i + 4] = s_o
+                d_pre = C(d_o, WA.bwd_operand(r_skip), None, mg_src=pre, lengths=lengths, flags=K.CONV_GATE_BWD | K.CONV_MASK_OUT, gate_h=H)
             else:
-                dw_rs = torch.empty(1, 2 * H, H, device=d_o.device, dtype=torch.float32)
-                WG(acts, d_h, 1, out=dw_rs[:, :H])
-                WG(acts, d_o, 1, out=dw_rs[:, H:])
-                grads[4 * i + 2] = dw_rs
-                grads[4 * i + 3] = torch.cat([d_h.sum((0, 1), dtype=torch.float32), s_o])
+                grads[5 * i + 2] = WG(acts, d_h, 1, out=r_res.dw)
+                grads[5 * i + 4] = torch.cat([d_h.sum((0, 1), dtype=torch.float32), s_o])
                 # partial d(acts) from the residual branch, held in the left half of a 2H-wide buffer so that
                 # its row pitch equals that of the GATE_BWD output (the kernel shares ldy between y, res, mg_src)
                 tmp = torch.empty_like(pre)[..., :H]
-                C(d_h, flip_t(w_rs[:, :H]), None, out=tmp)
-                d_pre = C(d_o, flip_t(w_rs[:, H:]), None, res=tmp, mg_src=pre, lengths=lengths,
+                C(d_h, WA.bwd_operand(r_res), None, out=tmp)
+                d_pre = C(d_o, WA.bwd_operand(r_skip), None, res=tmp, mg_src=pre, lengths=lengths,
                           flags=K.CONV_GATE_BWD | K.CONV_MASK_OUT, gate_h=H)
-            grads[4 * i] = WG(h, d_pre, k, dil=d, pad=pad)
+            grads[5 * i] = WG(h, d_pre, k, dil=d, pad=pad, out=r_in.dw)
             s_b = d_pre.sum(1, dtype=torch.float32)                       # [b, 2H]: gradient of cond[i]
-            grads[4 * i + 1] = s_b.sum(0)
+            grads[5 * i + 1] = s_b.sum(0)
             if dcond is not None:
                 dcond.append(s_b)
-            d_h = C(d_pre, flip_t(w_in), None, res=d_h, lengths=lengths, dil=d, pad=pad,
+            d_h = C(d_pre, WA.bwd_operand(r_in), None, res=d_h, lengths=lengths, dil=d, pad=pad,
                     flags=K.CONV_MASK_OUT | (K.CONV_RES_AFTER if d_h is not None else 0))
         dc = torch.stack(dcond[::-1], 0) if dcond is not None else None
         return (None, None, d_h, None, dc, *grads)

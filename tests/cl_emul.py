@@ -110,3 +110,78 @@ def install(pkg):
     pkg.kernels.conv1d_cl_wgrad_raw = conv1d_cl_wgrad_raw
     dcl.convt_fold = convt_fold
     dcl.convt_unfold = convt_unfold
+
+
+def weight_prep(arena):
+    """Emulates vits_weight_prep on an arena (tests only): fills w_fwd / w_bwd from the parameters."""
+    for s, f, bw in zip(arena.specs, arena.fwd, arena.bwd):
+        v = s.v.detach().float()
+        if s.g is not None:
+            v = v * (s.g.detach().float() / torch.linalg.vector_norm(v, 2, dim=(1, 2), keepdim=True))
+        if s.transpose:                                   # [c_in][c_out][k] -> [1][k*c_out][c_in_p]
+            w = v.permute(2, 1, 0).reshape(1, s.k * s.c_out, s.c_in)
+            f.zero_(); f[:, :, : s.c_in] = w.to(f.dtype)
+            bw.zero_(); bw[:, : s.c_in, :] = w.transpose(1, 2).to(bw.dtype)
+        else:
+            w = v[s.row_lo:s.row_lo + s.n_rows].permute(2, 0, 1)          # [k][rows][c_in]
+            f.zero_(); f[:, : s.n_rows, : s.c_in] = w.to(f.dtype)
+            bw.zero_(); bw[:, : s.c_in, : s.n_rows] = w.flip(0).transpose(1, 2).to(bw.dtype)
+
+
+def weight_prep_bwd(arena):
+    """Emulates vits_weight_prep_bwd: arena.dw (kernel layout) -> arena.dparam_views."""
+    for v in arena.dparam_views:
+        v.zero_()
+    pid = {id(p): i for i, p in enumerate(arena.params)}
+    for s, dwv in zip(arena.specs, arena.dws):
+        v = s.v.detach().float()
+        if s.transpose:
+            dw = dwv[0, :, : s.c_in].reshape(s.k, s.c_out, s.c_in).permute(2, 1, 0)      # [c_in][c_out][k]
+            rows = slice(0, s.c_in)
+        else:
+            dw = dwv[:, : s.n_rows, : s.c_in].permute(1, 2, 0)                              # [rows][c_in][k]
+            rows = slice(s.row_lo, s.row_lo + s.n_rows)
+        vr = v[rows]
+        if s.g is None:
+            arena.dparam_views[pid[id(s.v)]][rows] = dw
+        else:
+            n = torch.linalg.vector_norm(vr, 2, dim=(1, 2), keepdim=True)
+            dot = (dw * vr).sum((1, 2), keepdim=True)
+            gg = s.g.detach().float()[rows]
+            arena.dparam_views[pid[id(s.v)]][rows] = (gg / n) * (dw - vr * dot / (n * n))
+            arena.dparam_views[pid[id(s.g)]][rows] = dot / n
+
+
+class _FakeLib:
+    """Stands in for _lib.lib() inside weight_arena on a machine without a GPU."""
+
+    def __init__(self, real, arenas):
+        self._real, self._arenas = real, arenas
+
+    def vits_weight_prep(self, table, n, rows, dtype, wf, wb, stream):
+        weight_prep(self._arenas[wf]); return 0
+
+    def vits_weight_prep_bwd(self, table, n, rows, dw, dparam, stream):
+        weight_prep_bwd(self._arenas[dw]); return 0
+
+    def __getattr__(self, k):
+        return getattr(self._real, k)
+
+
+def install_arena_emulation(monkeypatch):
+    """Route weight_arena's two kernel launches to the torch emulation above (CPU tests)."""
+    import importlib
+    WA = importlib.import_module("personalized_text-to-speech_amd.weight_arena")
+    L = importlib.import_module("personalized_text-to-speech_amd._lib")
+    arenas = {}
+    orig_init = WA.WeightArena.__init__
+
+    def init(self, specs, dtype):
+        orig_init(self, specs, dtype)
+        arenas[self.w_fwd.data_ptr()] = self
+        arenas[self.dw.data_ptr()] = self
+
+    monkeypatch.setattr(WA.WeightArena, "__init__", init)
+    fake = _FakeLib(L.lib(), arenas)
+    monkeypatch.setattr(WA._lib, "lib", lambda: fake)
+    monkeypatch.setattr(WA._lib, "stream_ptr", lambda: 0)

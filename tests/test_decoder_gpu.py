@@ -18,12 +18,15 @@ def run_both(pkg, net, cfg_model, z, g, amp):
     of the ORACLE graph itself under torch.autocast(bf16) — i.e. of the reference's own AMP numerics —
     against its fp32 run; the product's bf16 kernels must not be worse than that."""
     dec = net.dec
-    sd = {("dec." + k): v.detach().clone().requires_grad_(True) for k, v in dec.state_dict().items()}
-    z_o, g_o = z.clone().requires_grad_(True), g.clone().requires_grad_(True)
-    y_o = O.generator(sd, cfg_model, z_o, g_o)
-    probe = torch.randn_like(y_o)
-    (y_o * probe).sum().backward()
-    ref = (y_o.detach(), z_o.grad, g_o.grad, {k: v.grad for k, v in sd.items()})
+    # fp32 oracle on the CPU: MIOpen's fp32 solvers (Winograd, find-mode dependent) are not a stable yardstick
+    sd_c = {("dec." + k): v.detach().cpu().clone().requires_grad_(True) for k, v in dec.state_dict().items()}
+    z_o, g_o = z.cpu().clone().requires_grad_(True), g.cpu().clone().requires_grad_(True)
+    y_o = O.generator(sd_c, cfg_model, z_o, g_o)
+    probe_c = torch.randn_like(y_o)
+    (y_o * probe_c).sum().backward()
+    probe = probe_c.to(z.device)
+    ref = (y_o.detach().to(z.device), z_o.grad.to(z.device), g_o.grad.to(z.device), {k: v.grad.to(z.device) for k, v in sd_c.items()})
+    sd = {k: v.detach().to(z.device) for k, v in sd_c.items()}
     yard = None
     if amp:
         sd2 = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}

@@ -57,7 +57,7 @@ def _worker(rank, world, port, out):
         t = p.data.clone()
         dist.broadcast(t, 0)
         same_params &= bool(torch.equal(t, p.data))
-    out[rank] = (ok, same_params, float(unused.grad.abs().sum()))
+    out[rank] = (ok, same_params, float(unused.grad.abs().sum()), all(p.grad.data_ptr() == v.data_ptr() for (_, pl, vs) in buckets.buckets for p, v in zip(pl, vs)))
     dist.destroy_process_group()
 
 
@@ -73,5 +73,5 @@ def test_grad_buckets_two_ranks():
             p.join(120)
             assert p.exitcode == 0
         for r in range(2):
-            ok, same, unused = out[r]
-            assert ok and same and unused == 0.0
+            ok, same, unused, flat_views = out[r]
+            assert ok and same and unused == 0.0 and flat_views
