@@ -191,6 +191,53 @@ int vits_weight_prep(const vits_prep_entry* entries, int n_entries, int total_ro
 int vits_weight_prep_bwd(const vits_prep_entry* entries, int n_entries, int total_rows, const float* dw,
                          float* dparam, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Row-wise channels-last kernels ([rows][c], c <= 1024; dtype VITS_DT_F32 or VITS_DT_BF16 for the
+ * activations, parameters always float32).
+ *
+ * vits_ln_act_cl:  y = [res +] act( LayerNorm_c(x) * gamma + beta ),  act 0 = identity, 1 = GELU (erf).
+ *   Replaces modules.LayerNorm.forward (modules.py:29-32: transpose, F.layer_norm over channels,
+ *   transpose) fused with the F.gelu and `x = x + y` around it in DDSConv (modules.py:100-107) and with
+ *   the post-norm residual of attentions.Encoder (attentions.py:41-46: res + LayerNorm is written
+ *   there as LayerNorm(x + y); use res = NULL and pass x + y).
+ * vits_ln_act_cl_bwd: dx, and dgamma / dbeta (+)= per-channel sums (reproducible two-stage sums).
+ *   The gradient of `res` is dy itself.
+ * vits_dwconv_cl:  y[b,t,c] = bias[c] + sum_j w[c][j] * xm[b, t + (j - (k-1)/2) * dil, c],  xm = x with rows
+ *   t >= lengths[b] read as zero (lengths may be NULL), "same" padding, odd k <= 7.
+ *   Replaces the groups=channels Conv1d of DDSConv (modules.py:84-86,98: convs_sep[i](x * x_mask)).
+ * vits_dwconv_cl_bwd: dx (masked like x), dw [c][k] and dbias [c] (+)=.
+ * workspace: at least vits_rowops_workspace(rows, c, k) bytes (k = 1 for the LayerNorm backward).
+ * ------------------------------------------------------------------------------------------ */
+size_t vits_rowops_workspace(int rows, int c, int k);
+int vits_ln_act_cl(int dtype, const void* x, const float* gamma, const float* beta, const void* res, void* y,
+                   int rows, int c, float eps, int act, void* stream);
+int vits_ln_act_cl_bwd(int dtype, const void* x, const float* gamma, const float* beta, const void* dy, void* dx,
+                       float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, int rows, int c,
+                       float eps, int act, int accumulate, void* stream);
+int vits_dwconv_cl(int dtype, const void* x, const float* w, const float* bias, const int32_t* lengths, void* y,
+                   int b, int t, int c, int k, int dil, void* stream);
+int vits_dwconv_cl_bwd(int dtype, const void* x, const float* w, const int32_t* lengths, const void* dy, void* dx,
+                       float* dw, float* dbias, void* workspace, size_t workspace_bytes, int b, int t, int c, int k,
+                       int dil, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Piecewise rational-quadratic spline, linear tails, 10 bins (forward, inverse, backward).
+ *
+ * Replaces: transforms.piecewise_rational_quadratic_transform(inputs, unnormalized_widths,
+ *           unnormalized_heights, unnormalized_derivatives, inverse, tails='linear', tail_bound)
+ *           (transforms.py:12-43, :55-95, :97-193) as called from modules.py:375-384, and its autograd.
+ *   x [n] float32;  h [n][ldh] (float32 or bf16): columns 0..9 widths, 10..19 heights, 20..28 interior
+ *   derivatives, exactly the ConvFlow projection's channel order (modules.py:371-377); widths and
+ *   heights are multiplied by hscale (= 1/sqrt(filter_channels), modules.py:373-374) inside;
+ *   y, logabsdet [n] float32.  Outside [-tail_bound, tail_bound] (inclusive): y = x, logabsdet = 0.
+ *   Unlike the reference, a call whose inputs ALL lie outside the interval does not raise.
+ *   backward: gx [n] and gh [n][ldh] (gradient wrt the raw h, columns >= 29 zeroed) from gy, glogabsdet.
+ * ------------------------------------------------------------------------------------------ */
+int vits_rq_spline(int h_dtype, const float* x, const void* h, int ldh, float hscale, int inverse, float tail_bound,
+                   float* y, float* logabsdet, int n, void* stream);
+int vits_rq_spline_bwd(int h_dtype, const float* x, const void* h, int ldh, float hscale, int inverse, float tail_bound,
+                       const float* gy, const float* glogabsdet, float* gx, void* gh, int n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,6 +23,13 @@ SIGNATURES = {
     "vits_abi_version": (c_int, []),
     "vits_last_error": (ctypes.c_char_p, []),
     "vits_mas_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "vits_rq_spline": (c_int, [c_int, c_void_p, c_void_p, c_int, c_float, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p]),
+    "vits_rq_spline_bwd": (c_int, [c_int, c_void_p, c_void_p, c_int, c_float, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "vits_rowops_workspace": (c_size_t, [c_int, c_int, c_int]),
+    "vits_ln_act_cl": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p]),
+    "vits_ln_act_cl_bwd": (c_int, [c_int] + [c_void_p] * 8 + [c_size_t, c_int, c_int, c_float, c_int, c_int, c_void_p]),
+    "vits_dwconv_cl": (c_int, [c_int] + [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
+    "vits_dwconv_cl_bwd": (c_int, [c_int] + [c_void_p] * 8 + [c_size_t] + [c_int] * 6 + [c_void_p]),
     "vits_weight_prep": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "vits_weight_prep_bwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "vits_convt_fold_cl": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),

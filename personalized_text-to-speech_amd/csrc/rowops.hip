@@ -1,0 +1,248 @@
+// Row-wise channels-last kernels of the duration predictor / text encoder:
+//   vits_ln_act_cl      y = [res +] act( LayerNorm_c(x) * gamma + beta )          (fwd, bwd)
+//   vits_dwconv_cl      depth-wise dilated convolution over time, masked input    (fwd, bwd)
+//
+// Replaces (reference): modules.LayerNorm (modules.py:20-32: F.layer_norm over the channel dim after
+// two transposes), F.gelu, the `x = x + y` residual and the depth-separable conv of modules.DDSConv
+// (modules.py:95-108), and the post-norm residual LayerNorms of attentions.Encoder (attentions.py:41-46).
+//
+// Tensors are [rows][C] with C <= 1024; one workgroup walks a chunk of rows with ONE THREAD PER
+// CHANNEL (coalesced row reads; the per-row mean/variance is a block reduction, the per-channel
+// parameter gradients are plain per-thread sums over the chunk, written as per-workgroup partials
+// and summed by a second tiny kernel in a fixed order => reproducible, no float atomics).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float to_f(float v) { return v; }
+__device__ __forceinline__ float to_f(__bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ __bf16 from_f<__bf16>(float v) { return (__bf16)v; }
+
+constexpr float kInvSqrt2 = 0.70710678118654752440f;
+constexpr float kInvSqrt2Pi = 0.39894228040143267794f;
+__device__ __forceinline__ float gelu_f(float u) { return 0.5f * u * (1.0f + erff(u * kInvSqrt2)); }
+__device__ __forceinline__ float gelu_grad(float u) {
+  return 0.5f * (1.0f + erff(u * kInvSqrt2)) + u * kInvSqrt2Pi * __expf(-0.5f * u * u);
+}
+
+// sum over the workgroup (blockDim.x multiple of 64, <= 1024); every thread gets the result
+__device__ __forceinline__ float block_sum(float v, float* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int w = 0; w < nw; ++w) s += red[w];
+  return s;
+}
+
+template <typename T>
+__global__ void ln_act_fwd(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                           const T* __restrict__ res, T* __restrict__ y, int rows, int C, float eps, int act, int rows_per_wg) {
+  __shared__ float red[16];
+  const int c = threadIdx.x;
+  const bool on = c < C;
+  const float g = on ? gamma[c] : 0.f, bt = on ? beta[c] : 0.f;
+  const int r0 = blockIdx.x * rows_per_wg;
+  for (int r = r0; r < r0 + rows_per_wg && r < rows; ++r) {
+    const float v = on ? to_f(x[(size_t)r * C + c]) : 0.f;
+    const float mean = block_sum(v, red) / C;
+    const float d = on ? v - mean : 0.f;
+    const float var = block_sum(d * d, red) / C;
+    float u = d * rsqrtf(var + eps) * g + bt;
+    if (act == 1) u = gelu_f(u);
+    if (on) {
+      if (res) u += to_f(res[(size_t)r * C + c]);
+      y[(size_t)r * C + c] = from_f<T>(u);
+    }
+  }
+}
+
+template <typename T>
+__global__ void ln_act_bwd(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                           const T* __restrict__ dy, T* __restrict__ dx, float* __restrict__ part, int rows, int C, float eps,
+                           int act, int rows_per_wg) {
+  __shared__ float red[16];
+  const int c = threadIdx.x;
+  const bool on = c < C;
+  const float g = on ? gamma[c] : 0.f, bt = on ? beta[c] : 0.f;
+  float dg = 0.f, db = 0.f;
+  const int r0 = blockIdx.x * rows_per_wg;
+  for (int r = r0; r < r0 + rows_per_wg && r < rows; ++r) {
+    const float v = on ? to_f(x[(size_t)r * C + c]) : 0.f;
+    const float mean = block_sum(v, red) / C;
+    const float d = on ? v - mean : 0.f;
+    const float var = block_sum(d * d, red) / C;
+    const float rstd = rsqrtf(var + eps);
+    const float xh = d * rstd;
+    float du = on ? to_f(dy[(size_t)r * C + c]) : 0.f;
+    if (act == 1) du *= gelu_grad(xh * g + bt);
+    dg += du * xh;
+    db += du;
+    const float a = du * g;
+    const float m1 = block_sum(a, red) / C;
+    const float m2 = block_sum(a * xh, red) / C;
+    if (on) dx[(size_t)r * C + c] = from_f<T>(rstd * (a - m1 - xh * m2));
+  }
+  if (on) {
+    part[(size_t)blockIdx.x * 2 * C + c] = dg;
+    part[(size_t)blockIdx.x * 2 * C + C + c] = db;
+  }
+}
+
+// out[j] (+)= sum_w part[w * stride + j], j < n   (fixed order)
+__global__ void reduce_partials(const float* __restrict__ part, float* __restrict__ out, int n, int W, int stride, int accumulate) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  float s = accumulate ? out[j] : 0.f;
+  for (int w = 0; w < W; ++w) s += part[(size_t)w * stride + j];
+  out[j] = s;
+}
+
+// ---------------------------------------------------------------- depth-wise conv
+template <typename T>
+__global__ void dwconv_fwd(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                           const int* __restrict__ lengths, T* __restrict__ y, int B, int Tn, int C, int k, int dil,
+                           int rows_per_wg) {
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  float wk[8];
+  for (int j = 0; j < k; ++j) wk[j] = w[c * k + j];
+  const float bs = bias ? bias[c] : 0.f;
+  const int half = (k - 1) / 2;
+  const int r0 = blockIdx.x * rows_per_wg;
+  for (int r = r0; r < r0 + rows_per_wg && r < B * Tn; ++r) {
+    const int b = r / Tn, t = r % Tn;
+    const int len = lengths ? lengths[b] : Tn;
+    float acc = bs;
+    for (int j = 0; j < k; ++j) {
+      const int ti = t + (j - half) * dil;
+      if (ti >= 0 && ti < Tn && ti < len) acc += wk[j] * to_f(x[((size_t)b * Tn + ti) * C + c]);
+    }
+    y[(size_t)r * C + c] = from_f<T>(acc);
+  }
+}
+
+template <typename T>
+__global__ void dwconv_bwd(const T* __restrict__ x, const float* __restrict__ w, const int* __restrict__ lengths,
+                           const T* __restrict__ dy, T* __restrict__ dx, float* __restrict__ part, int B, int Tn, int C, int k,
+                           int dil, int rows_per_wg) {
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  float wk[8], dw[8];
+  for (int j = 0; j < k; ++j) { wk[j] = w[c * k + j]; dw[j] = 0.f; }
+  float db = 0.f;
+  const int half = (k - 1) / 2;
+  const int r0 = blockIdx.x * rows_per_wg;
+  for (int r = r0; r < r0 + rows_per_wg && r < B * Tn; ++r) {
+    const int b = r / Tn, t = r % Tn;
+    const int len = lengths ? lengths[b] : Tn;
+    // dx[t] = mask[t] * sum_j w[j] * dy[t - (j-half)*dil]
+    float acc = 0.f;
+    if (t < len) {
+      for (int j = 0; j < k; ++j) {
+        const int to = t - (j - half) * dil;
+        if (to >= 0 && to < Tn) acc += wk[j] * to_f(dy[((size_t)b * Tn + to) * C + c]);
+      }
+    }
+    dx[(size_t)r * C + c] = from_f<T>(acc);
+    // dw[j] += dy[t] * xm[t + (j-half)*dil]
+    const float g = to_f(dy[(size_t)r * C + c]);
+    db += g;
+    for (int j = 0; j < k; ++j) {
+      const int ti = t + (j - half) * dil;
+      if (ti >= 0 && ti < Tn && ti < len) dw[j] += g * to_f(x[((size_t)b * Tn + ti) * C + c]);
+    }
+  }
+  float* P = part + (size_t)blockIdx.x * (k + 1) * C;
+  for (int j = 0; j < k; ++j) P[c * k + j] = dw[j];
+  P[k * C + c] = db;
+}
+
+int pick_rows_per_wg(int rows) {
+  int wgs = rows < 512 ? rows : 512;
+  if (wgs < 1) wgs = 1;
+  return (rows + wgs - 1) / wgs;
+}
+
+}  // namespace
+
+extern "C" size_t vits_rowops_workspace(int rows, int c, int k) {
+  const int rpw = pick_rows_per_wg(rows);
+  const int wgs = (rows + rpw - 1) / rpw;
+  const int per = (k + 1) > 2 ? (k + 1) : 2;
+  return (size_t)wgs * per * c * sizeof(float);
+}
+
+extern "C" int vits_ln_act_cl(int dtype, const void* x, const float* gamma, const float* beta, const void* res, void* y,
+                              int rows, int c, float eps, int act, void* stream) {
+  if (!x || !gamma || !beta || !y || rows <= 0 || c <= 0) return VITS_E_BADARG;
+  if (c > 1024 || act < 0 || act > 1) return VITS_E_UNSUPPORTED;
+  const int threads = ((c + 63) / 64) * 64, rpw = pick_rows_per_wg(rows), wgs = (rows + rpw - 1) / rpw;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == VITS_DT_BF16)
+    hipLaunchKernelGGL(ln_act_fwd<__bf16>, dim3(wgs), dim3(threads), 0, s, (const __bf16*)x, gamma, beta, (const __bf16*)res, (__bf16*)y, rows, c, eps, act, rpw);
+  else if (dtype == VITS_DT_F32)
+    hipLaunchKernelGGL(ln_act_fwd<float>, dim3(wgs), dim3(threads), 0, s, (const float*)x, gamma, beta, (const float*)res, (float*)y, rows, c, eps, act, rpw);
+  else return VITS_E_UNSUPPORTED;
+  return vits::check_launch("vits_ln_act_cl");
+}
+
+extern "C" int vits_ln_act_cl_bwd(int dtype, const void* x, const float* gamma, const float* beta, const void* dy, void* dx,
+                                  float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, int rows, int c,
+                                  float eps, int act, int accumulate, void* stream) {
+  if (!x || !gamma || !beta || !dy || !dx || !dgamma || !dbeta || !workspace || rows <= 0 || c <= 0) return VITS_E_BADARG;
+  if (c > 1024 || act < 0 || act > 1) return VITS_E_UNSUPPORTED;
+  if (workspace_bytes < vits_rowops_workspace(rows, c, 1)) return VITS_E_BADARG;
+  const int threads = ((c + 63) / 64) * 64, rpw = pick_rows_per_wg(rows), wgs = (rows + rpw - 1) / rpw;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float* part = static_cast<float*>(workspace);
+  if (dtype == VITS_DT_BF16)
+    hipLaunchKernelGGL(ln_act_bwd<__bf16>, dim3(wgs), dim3(threads), 0, s, (const __bf16*)x, gamma, beta, (const __bf16*)dy, (__bf16*)dx, part, rows, c, eps, act, rpw);
+  else if (dtype == VITS_DT_F32)
+    hipLaunchKernelGGL(ln_act_bwd<float>, dim3(wgs), dim3(threads), 0, s, (const float*)x, gamma, beta, (const float*)dy, (float*)dx, part, rows, c, eps, act, rpw);
+  else return VITS_E_UNSUPPORTED;
+  // partials are [wg][2][c]: dgamma then dbeta
+  hipLaunchKernelGGL(reduce_partials, dim3((c + 255) / 256), dim3(256), 0, s, part, dgamma, c, wgs, 2 * c, accumulate);
+  hipLaunchKernelGGL(reduce_partials, dim3((c + 255) / 256), dim3(256), 0, s, part + c, dbeta, c, wgs, 2 * c, accumulate);
+  return vits::check_launch("vits_ln_act_cl_bwd");
+}
+
+extern "C" int vits_dwconv_cl(int dtype, const void* x, const float* w, const float* bias, const int32_t* lengths, void* y,
+                              int b, int t, int c, int k, int dil, void* stream) {
+  if (!x || !w || !y || b <= 0 || t <= 0 || c <= 0 || k <= 0 || dil <= 0) return VITS_E_BADARG;
+  if (c > 1024 || k > 8 || (k % 2) == 0) return VITS_E_UNSUPPORTED;
+  const int rows = b * t, threads = ((c + 63) / 64) * 64, rpw = pick_rows_per_wg(rows), wgs = (rows + rpw - 1) / rpw;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == VITS_DT_BF16)
+    hipLaunchKernelGGL(dwconv_fwd<__bf16>, dim3(wgs), dim3(threads), 0, s, (const __bf16*)x, w, bias, lengths, (__bf16*)y, b, t, c, k, dil, rpw);
+  else if (dtype == VITS_DT_F32)
+    hipLaunchKernelGGL(dwconv_fwd<float>, dim3(wgs), dim3(threads), 0, s, (const float*)x, w, bias, lengths, (float*)y, b, t, c, k, dil, rpw);
+  else return VITS_E_UNSUPPORTED;
+  return vits::check_launch("vits_dwconv_cl");
+}
+
+extern "C" int vits_dwconv_cl_bwd(int dtype, const void* x, const float* w, const int32_t* lengths, const void* dy, void* dx,
+                                  float* dw, float* dbias, void* workspace, size_t workspace_bytes, int b, int t, int c, int k,
+                                  int dil, int accumulate, void* stream) {
+  if (!x || !w || !dy || !dx || !dw || !dbias || !workspace || b <= 0 || t <= 0 || c <= 0 || k <= 0 || dil <= 0) return VITS_E_BADARG;
+  if (c > 1024 || k > 8 || (k % 2) == 0) return VITS_E_UNSUPPORTED;
+  const int rows = b * t;
+  if (workspace_bytes < vits_rowops_workspace(rows, c, k)) return VITS_E_BADARG;
+  const int threads = ((c + 63) / 64) * 64, rpw = pick_rows_per_wg(rows), wgs = (rows + rpw - 1) / rpw;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float* part = static_cast<float*>(workspace);
+  if (dtype == VITS_DT_BF16)
+    hipLaunchKernelGGL(dwconv_bwd<__bf16>, dim3(wgs), dim3(threads), 0, s, (const __bf16*)x, w, lengths, (const __bf16*)dy, (__bf16*)dx, part, b, t, c, k, dil, rpw);
+  else if (dtype == VITS_DT_F32)
+    hipLaunchKernelGGL(dwconv_bwd<float>, dim3(wgs), dim3(threads), 0, s, (const float*)x, w, lengths, (const float*)dy, (float*)dx, part, b, t, c, k, dil, rpw);
+  else return VITS_E_UNSUPPORTED;
+  // partial rows are [(k+1)*c]: first k*c = dw[c][k], then c = dbias
+  hipLaunchKernelGGL(reduce_partials, dim3((k * c + 255) / 256), dim3(256), 0, s, part, dw, k * c, wgs, (k + 1) * c, accumulate);
+  hipLaunchKernelGGL(reduce_partials, dim3((c + 255) / 256), dim3(256), 0, s, part + (size_t)k * c, dbias, c, wgs, (k + 1) * c, accumulate);
+  return vits::check_launch("vits_dwconv_cl_bwd");
+}
