@@ -48,45 +48,63 @@ class StochasticDurationPredictor(nn.Module):
             self.cond = Conv1d(gin_channels, filter_channels, 1)
 
     def forward(self, x, x_mask, w=None, g=None, reverse=False, noise_scale=1.0):
-        x = self.pre(torch.detach(x))
+        """Reference call surface ([b, c, t] tensors); everything inside runs channels-last: the 1x1
+        convolutions on the matrix cores, DDSConv on the row kernels, the splines in one launch each."""
+        from . import wn_cl
+        dtype = wn_cl.compute_dtype()
+        lengths = wn_cl.lengths_of(x_mask)
+        m = x_mask.transpose(1, 2)                                     # [b, t, 1]
+        xc = wn_cl.conv_cl(torch.detach(x).transpose(1, 2).contiguous(), wn_cl.weight_of(self.pre), self.pre.bias, dtype=dtype)
         if g is not None:
-            x = x + self.cond(torch.detach(g))
-        x = self.convs(x, x_mask)
-        x = self.proj(x) * x_mask
+            xc = xc + self.cond(torch.detach(g)).transpose(1, 2).to(dtype)
+        xc = self.convs.forward_cl(xc, lengths, m)
+        xc = wn_cl.conv_cl(xc, wn_cl.weight_of(self.proj), self.proj.bias, lengths, mask_out=True, dtype=dtype)
+
+        def run(flow, z, cond):
+            if isinstance(flow, modules.Flip):
+                return torch.flip(z, [2]), None
+            if isinstance(flow, modules.ElementwiseAffine):
+                mm, ls = flow.m.view(1, 1, -1), flow.logs.view(1, 1, -1)
+                if not reverse:
+                    return (mm + torch.exp(ls) * z) * m, torch.sum(ls * m, [1, 2])
+                return (z - mm) * torch.exp(-ls) * m, None
+            out = flow.forward_cl(z, lengths, m, cond, reverse)
+            return (out[0], out[1]) if not reverse else (out, None)
 
         if not reverse:
             assert w is not None
-            logdet_tot_q = 0
-            h_w = self.post_pre(w)
-            h_w = self.post_convs(h_w, x_mask)
-            h_w = self.post_proj(h_w) * x_mask
-            e_q = noise.randn(w.size(0), 2, w.size(2), device=x.device, dtype=x.dtype) * x_mask
-            z_q = e_q
+            w_cl = w.transpose(1, 2).float()                           # [b, t, 1]
+            h_w = (w_cl * self.post_pre.weight.view(1, 1, -1) + self.post_pre.bias).to(dtype)
+            h_w = self.post_convs.forward_cl(h_w, lengths, m)
+            h_w = wn_cl.conv_cl(h_w, wn_cl.weight_of(self.post_proj), self.post_proj.bias, lengths, mask_out=True, dtype=dtype)
+            e_q = noise.randn(w.size(0), 2, w.size(2), device=x.device, dtype=torch.float32).transpose(1, 2) * m
+            z_q, logdet_tot_q = e_q, 0
+            cond_q = xc + h_w
             for flow in self.post_flows:
-                z_q, logdet_q = flow(z_q, x_mask, g=(x + h_w))
-                logdet_tot_q = logdet_tot_q + logdet_q
-            z_u, z1 = torch.split(z_q, [1, 1], 1)
-            u = torch.sigmoid(z_u) * x_mask
-            z0 = (w - u) * x_mask
-            logdet_tot_q = logdet_tot_q + torch.sum((F.logsigmoid(z_u) + F.logsigmoid(-z_u)) * x_mask, [1, 2])
-            logq = torch.sum(-0.5 * (commons.LOG_2PI + (e_q ** 2)) * x_mask, [1, 2]) - logdet_tot_q
+                z_q, ld = run(flow, z_q, cond_q)
+                if ld is not None:
+                    logdet_tot_q = logdet_tot_q + ld
+            z_u, z1 = z_q[..., :1], z_q[..., 1:]
+            u = torch.sigmoid(z_u) * m
+            z0 = (w_cl - u) * m
+            logdet_tot_q = logdet_tot_q + torch.sum((F.logsigmoid(z_u) + F.logsigmoid(-z_u)) * m, [1, 2])
+            logq = torch.sum(-0.5 * (commons.LOG_2PI + (e_q ** 2)) * m, [1, 2]) - logdet_tot_q
 
-            logdet_tot = 0
-            z0, logdet = self.log_flow(z0, x_mask)
-            logdet_tot = logdet_tot + logdet
-            z = torch.cat([z0, z1], 1)
+            z0 = torch.log(torch.clamp_min(z0, 1e-5)) * m             # modules.Log
+            logdet_tot = torch.sum(-z0, [1, 2])
+            z = torch.cat([z0, z1], -1)
             for flow in self.flows:
-                z, logdet = flow(z, x_mask, g=x, reverse=reverse)
-                logdet_tot = logdet_tot + logdet
-            nll = torch.sum(0.5 * (commons.LOG_2PI + (z ** 2)) * x_mask, [1, 2]) - logdet_tot
-            return nll + logq                                     # [b]
+                z, ld = run(flow, z, xc)
+                if ld is not None:
+                    logdet_tot = logdet_tot + ld
+            nll = torch.sum(0.5 * (commons.LOG_2PI + (z ** 2)) * m, [1, 2]) - logdet_tot
+            return nll + logq                                          # [b]
         flows = list(reversed(self.flows))
-        flows = flows[:-2] + [flows[-1]]                          # models.py:88-89 "remove a useless vflow"
-        z = noise.randn(x.size(0), 2, x.size(2), device=x.device, dtype=x.dtype) * noise_scale
+        flows = flows[:-2] + [flows[-1]]                              # models.py:88-89 "remove a useless vflow"
+        z = noise.randn(x.size(0), 2, x.size(2), device=x.device, dtype=torch.float32).transpose(1, 2) * noise_scale
         for flow in flows:
-            z = flow(z, x_mask, g=x, reverse=reverse)
-        z0, z1 = torch.split(z, [1, 1], 1)
-        return z0                                                 # logw
+            z, _ = run(flow, z, xc)
+        return z[..., :1].transpose(1, 2).to(x.dtype)                  # logw [b, 1, t]
 
 
 class DurationPredictor(nn.Module):

@@ -123,16 +123,32 @@ class DDSConv(nn.Module):
             self.norms_2.append(LayerNorm(channels))
 
     def forward(self, x, x_mask, g=None):
+        """Reference layout [b, c, t]; runs channels-last on the HIP row kernels + MFMA 1x1 convolution."""
+        from . import wn_cl
+        dtype = wn_cl.compute_dtype()
+        y = self.forward_cl(x.transpose(1, 2).to(dtype), wn_cl.lengths_of(x_mask), x_mask.transpose(1, 2),
+                            None if g is None else g.transpose(1, 2).to(dtype))
+        return y.transpose(1, 2).to(x.dtype)
+
+    def forward_cl(self, x, lengths, mask_cl, g=None):
+        """x [b, t, c] channels-last (compute dtype).  Per layer (modules.py:97-107): masked depth-wise
+        dilated conv -> LayerNorm+GELU -> 1x1 conv (matrix cores) -> LayerNorm+GELU (+ residual when
+        dropout is off) : four launches."""
+        from . import rowops, wn_cl
         if g is not None:
             x = x + g
+        drop = self.training and self.p_dropout > 0
         for i in range(self.n_layers):
-            y = self.convs_sep[i](x * x_mask)
-            y = F.gelu(self.norms_1[i](y))
-            y = self.convs_1x1[i](y)
-            y = F.gelu(self.norms_2[i](y))
-            y = self.drop(y)
-            x = x + y
-        return x * x_mask
+            sep = self.convs_sep[i]
+            y = rowops.dwconv(x, sep.weight, sep.bias, lengths, sep.dilation)
+            y = rowops.ln_act(y, self.norms_1[i].gamma, self.norms_1[i].beta, None, self.norms_1[i].eps, 1)
+            y = wn_cl.conv_cl(y, wn_cl.weight_of(self.convs_1x1[i]), self.convs_1x1[i].bias, dtype=x.dtype)
+            if drop:
+                y = rowops.ln_act(y, self.norms_2[i].gamma, self.norms_2[i].beta, None, self.norms_2[i].eps, 1)
+                x = x + self.drop(y)
+            else:
+                x = rowops.ln_act(y, self.norms_2[i].gamma, self.norms_2[i].beta, x, self.norms_2[i].eps, 1)
+        return x * mask_cl.to(x.dtype)
 
 
 class WN(nn.Module):
@@ -301,17 +317,30 @@ class ConvFlow(nn.Module):
         self.proj.bias.data.zero_()
 
     def forward(self, x, x_mask, g=None, reverse=False):
-        x0, x1 = torch.split(x, [self.half_channels] * 2, 1)
-        h = self.pre(x0)
-        h = self.convs(h, x_mask, g=g)
-        h = self.proj(h) * x_mask
-        b, c, t = x0.shape
-        h = h.reshape(b, c, -1, t).permute(0, 1, 3, 2)                 # [b, c, t, 3*bins-1]
-        uw = h[..., :self.num_bins] / math.sqrt(self.filter_channels)
-        uh = h[..., self.num_bins:2 * self.num_bins] / math.sqrt(self.filter_channels)
-        ud = h[..., 2 * self.num_bins:]
-        x1, logabsdet = piecewise_rational_quadratic_transform(x1, uw, uh, ud, inverse=reverse, tails="linear", tail_bound=self.tail_bound)
-        x = torch.cat([x0, x1.to(x0.dtype)], 1) * x_mask
+        from . import wn_cl
+        dtype = wn_cl.compute_dtype()
+        out = self.forward_cl(x.transpose(1, 2), wn_cl.lengths_of(x_mask), x_mask.transpose(1, 2),
+                              None if g is None else g.transpose(1, 2).to(dtype), reverse)
         if not reverse:
-            return x, torch.sum(logabsdet * x_mask, [1, 2])
-        return x
+            return out[0].transpose(1, 2), out[1]
+        return out.transpose(1, 2)
+
+    def forward_cl(self, x, lengths, mask_cl, g=None, reverse=False):
+        """x [b, t, 2] float32 channels-last; g [b, t, filter_channels] (compute dtype) or None."""
+        from . import rowops, wn_cl
+        assert self.half_channels == 1, "the VITS duration flows transform one channel conditioned on the other"
+        dtype = wn_cl.compute_dtype()
+        b, t, _ = x.shape
+        x0, x1 = x[..., :1], x[..., 1:]
+        h = (x0 * self.pre.weight.view(1, 1, -1) + self.pre.bias).to(dtype)               # Conv1d(1, C, 1): outer product
+        h = self.convs.forward_cl(h, lengths, mask_cl, g)
+        n_par = self.num_bins * 3 - 1
+        pad = (-n_par) % 8                                                                   # 29 -> 32 output columns
+        hp = wn_cl.conv_cl(h, wn_cl.weight_of(self.proj, pad_out=pad), wn_cl.bias_of(self.proj, pad), lengths, mask_out=True, dtype=dtype)
+        y1, lad = rowops.rq_spline(x1.reshape(b * t), hp.reshape(b * t, n_par + pad), 1.0 / math.sqrt(self.filter_channels),
+                                   reverse, self.tail_bound)
+        m = mask_cl.to(x.dtype)
+        out = torch.cat([x0, y1.view(b, t, 1).to(x.dtype)], -1) * m
+        if not reverse:
+            return out, torch.sum(lad.view(b, t) * m[..., 0], 1)
+        return out

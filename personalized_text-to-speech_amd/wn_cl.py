@@ -83,16 +83,21 @@ def conv_cl(x, w, bias=None, lengths=None, dil=1, pad=0, in_slope=1.0, mask_in=F
     return ConvCLFn.apply(dtype or compute_dtype(), x, w, bias, lengths, dil, pad, in_slope, mask_in, mask_out)
 
 
-def weight_of(module, part=None, pad_in=0):
+def weight_of(module, part=None, pad_in=0, pad_out=0):
     """Kernel-layout weight of a conv module: the arena handle inside a weight_arena.scope, else the
-    torch-prepared fp32 tensor (optionally with zero-padded input channels)."""
+    torch-prepared fp32 tensor (optionally with zero-padded input / output channels)."""
     h = WA.handle_for(module, part)
     if h is not None:
         return h
     w = module.weight
-    if pad_in:
-        w = torch.nn.functional.pad(w, (0, 0, 0, pad_in))
+    if pad_in or pad_out:
+        w = torch.nn.functional.pad(w, (0, 0, 0, pad_in, 0, pad_out))
     return prep_conv(w)
+
+
+def bias_of(module, pad_out=0):
+    b = module.bias
+    return torch.nn.functional.pad(b, (0, pad_out)) if (pad_out and b is not None) else b
 
 
 class WNPlan:

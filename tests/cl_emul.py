@@ -185,3 +185,37 @@ def install_arena_emulation(monkeypatch):
     fake = _FakeLib(L.lib(), arenas)
     monkeypatch.setattr(WA._lib, "lib", lambda: fake)
     monkeypatch.setattr(WA._lib, "stream_ptr", lambda: 0)
+
+
+# ------------------------------------------------------------------ row kernels (rowops.py) emulation
+def ln_act(x, gamma, beta, res=None, eps=1e-5, act=0):
+    u = F.layer_norm(x.float(), (x.size(-1),), gamma.float(), beta.float(), eps)
+    if act == 1:
+        u = F.gelu(u)
+    if res is not None:
+        u = u + res.float()
+    return u.to(x.dtype)
+
+
+def dwconv(x, weight, bias, lengths, dil):
+    b, t, c = x.shape
+    k = weight.size(-1)
+    xf = x.float()
+    if lengths is not None:
+        xf = xf * (torch.arange(t, device=x.device)[None, :, None] < lengths[:, None, None])
+    y = F.conv1d(xf.transpose(1, 2), weight.float(), None if bias is None else bias.float(), padding=(k * dil - dil) // 2, dilation=dil, groups=c)
+    return y.transpose(1, 2).to(x.dtype)
+
+
+def rq_spline(x, h, hscale, inverse, tail_bound):
+    from oracle import vits_torch as O
+    hf = h.float()
+    return O.rq_spline(x.float(), hf[:, :10] * hscale, hf[:, 10:20] * hscale, hf[:, 20:29], bool(inverse), tail_bound)
+
+
+def install_rowops(monkeypatch):
+    import importlib
+    R = importlib.import_module("personalized_text-to-speech_amd.rowops")
+    monkeypatch.setattr(R, "ln_act", ln_act)
+    monkeypatch.setattr(R, "dwconv", dwconv)
+    monkeypatch.setattr(R, "rq_spline", rq_spline)

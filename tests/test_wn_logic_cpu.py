@@ -17,6 +17,7 @@ def emulated(pkg, monkeypatch):
     monkeypatch.setattr(pkg.kernels, "conv1d_cl_wgrad_raw", cl_emul.conv1d_cl_wgrad_raw)
     monkeypatch.setattr(dcl, "convt_fold", cl_emul.convt_fold)
     monkeypatch.setattr(dcl, "convt_unfold", cl_emul.convt_unfold)
+    cl_emul.install_rowops(monkeypatch)
     return pkg
 
 
