@@ -94,13 +94,23 @@ __global__ void ln_act_bwd(const T* __restrict__ x, const float* __restrict__ ga
   }
 }
 
-// out[j] (+)= sum_w part[w * stride + j], j < n   (fixed order)
-__global__ void reduce_partials(const float* __restrict__ part, float* __restrict__ out, int n, int W, int stride, int accumulate) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
-  float s = accumulate ? out[j] : 0.f;
-  for (int w = 0; w < W; ++w) s += part[(size_t)w * stride + j];
-  out[j] = s;
+// out[j] (+)= sum_w part[w * stride + j], j < n.  256 threads = 64 columns x 4 slices of w; the four
+// slice sums are combined in a fixed order => reproducible.
+__global__ __launch_bounds__(256) void reduce_partials(const float* __restrict__ part, float* __restrict__ out, int n, int W,
+                                                       int stride, int accumulate) {
+  __shared__ float sm[4][64];
+  const int col = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + col;
+  float s = 0.f;
+  if (j < n)
+    for (int w = slice; w < W; w += 4) s += part[(size_t)w * stride + j];
+  sm[slice][col] = s;
+  __syncthreads();
+  if (slice == 0 && j < n) {
+    float t = (accumulate ? out[j] : 0.f) + sm[0][col];
+    t += sm[1][col]; t += sm[2][col]; t += sm[3][col];
+    out[j] = t;
+  }
 }
 
 // ---------------------------------------------------------------- depth-wise conv
@@ -163,16 +173,19 @@ __global__ void dwconv_bwd(const T* __restrict__ x, const float* __restrict__ w,
   P[k * C + c] = db;
 }
 
-int pick_rows_per_wg(int rows) {
-  int wgs = rows < 512 ? rows : 512;
+// forward kernels: up to 512 workgroups; backward kernels write one partial row per workgroup, so
+// fewer (<= 96) keeps the second-stage sum short
+int pick_rows_per_wg(int rows, int max_wgs = 512) {
+  int wgs = rows < max_wgs ? rows : max_wgs;
   if (wgs < 1) wgs = 1;
   return (rows + wgs - 1) / wgs;
 }
+constexpr int kBwdWgs = 96;
 
 }  // namespace
 
 extern "C" size_t vits_rowops_workspace(int rows, int c, int k) {
-  const int rpw = pick_rows_per_wg(rows);
+  const int rpw = pick_rows_per_wg(rows, kBwdWgs);
   const int wgs = (rows + rpw - 1) / rpw;
   const int per = (k + 1) > 2 ? (k + 1) : 2;
   return (size_t)wgs * per * c * sizeof(float);
@@ -198,7 +211,7 @@ extern "C" int vits_ln_act_cl_bwd(int dtype, const void* x, const float* gamma, 
   if (!x || !gamma || !beta || !dy || !dx || !dgamma || !dbeta || !workspace || rows <= 0 || c <= 0) return VITS_E_BADARG;
   if (c > 1024 || act < 0 || act > 1) return VITS_E_UNSUPPORTED;
   if (workspace_bytes < vits_rowops_workspace(rows, c, 1)) return VITS_E_BADARG;
-  const int threads = ((c + 63) / 64) * 64, rpw = pick_rows_per_wg(rows), wgs = (rows + rpw - 1) / rpw;
+  const int threads = ((c + 63) / 64) * 64, rpw = pick_rows_per_wg(rows, kBwdWgs), wgs = (rows + rpw - 1) / rpw;
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* part = static_cast<float*>(workspace);
   if (dtype == VITS_DT_BF16)
@@ -207,8 +220,8 @@ extern "C" int vits_ln_act_cl_bwd(int dtype, const void* x, const float* gamma, 
     hipLaunchKernelGGL(ln_act_bwd<float>, dim3(wgs), dim3(threads), 0, s, (const float*)x, gamma, beta, (const float*)dy, (float*)dx, part, rows, c, eps, act, rpw);
   else return VITS_E_UNSUPPORTED;
   // partials are [wg][2][c]: dgamma then dbeta
-  hipLaunchKernelGGL(reduce_partials, dim3((c + 255) / 256), dim3(256), 0, s, part, dgamma, c, wgs, 2 * c, accumulate);
-  hipLaunchKernelGGL(reduce_partials, dim3((c + 255) / 256), dim3(256), 0, s, part + c, dbeta, c, wgs, 2 * c, accumulate);
+  hipLaunchKernelGGL(reduce_partials, dim3((c + 63) / 64), dim3(256), 0, s, part, dgamma, c, wgs, 2 * c, accumulate);
+  hipLaunchKernelGGL(reduce_partials, dim3((c + 63) / 64), dim3(256), 0, s, part + c, dbeta, c, wgs, 2 * c, accumulate);
   return vits::check_launch("vits_ln_act_cl_bwd");
 }
 
@@ -233,7 +246,7 @@ extern "C" int vits_dwconv_cl_bwd(int dtype, const void* x, const float* w, cons
   if (c > 1024 || k > 8 || (k % 2) == 0) return VITS_E_UNSUPPORTED;
   const int rows = b * t;
   if (workspace_bytes < vits_rowops_workspace(rows, c, k)) return VITS_E_BADARG;
-  const int threads = ((c + 63) / 64) * 64, rpw = pick_rows_per_wg(rows), wgs = (rows + rpw - 1) / rpw;
+  const int threads = ((c + 63) / 64) * 64, rpw = pick_rows_per_wg(rows, kBwdWgs), wgs = (rows + rpw - 1) / rpw;
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* part = static_cast<float*>(workspace);
   if (dtype == VITS_DT_BF16)
@@ -242,7 +255,7 @@ extern "C" int vits_dwconv_cl_bwd(int dtype, const void* x, const float* w, cons
     hipLaunchKernelGGL(dwconv_bwd<float>, dim3(wgs), dim3(threads), 0, s, (const float*)x, w, lengths, (const float*)dy, (float*)dx, part, b, t, c, k, dil, rpw);
   else return VITS_E_UNSUPPORTED;
   // partial rows are [(k+1)*c]: first k*c = dw[c][k], then c = dbias
-  hipLaunchKernelGGL(reduce_partials, dim3((k * c + 255) / 256), dim3(256), 0, s, part, dw, k * c, wgs, (k + 1) * c, accumulate);
-  hipLaunchKernelGGL(reduce_partials, dim3((c + 255) / 256), dim3(256), 0, s, part + (size_t)k * c, dbias, c, wgs, (k + 1) * c, accumulate);
+  hipLaunchKernelGGL(reduce_partials, dim3((k * c + 63) / 64), dim3(256), 0, s, part, dw, k * c, wgs, (k + 1) * c, accumulate);
+  hipLaunchKernelGGL(reduce_partials, dim3((c + 63) / 64), dim3(256), 0, s, part + (size_t)k * c, dbias, c, wgs, (k + 1) * c, accumulate);
   return vits::check_launch("vits_dwconv_cl_bwd");
 }
