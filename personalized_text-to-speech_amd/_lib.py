@@ -135,11 +135,15 @@ class KernelTimer:
         self.events.setdefault(name, []).append((e0, e1, units))
 
     def summary(self):
-        """name -> dict(calls, avg_ms, units_per_call); call after torch.cuda.synchronize()."""
+        """name -> dict(calls, total_ms, avg_ms, units_per_call); `units` may be a number or a tuple
+        (summed component-wise).  Call after torch.cuda.synchronize()."""
         out = {}
         for name, ev in self.events.items():
             ms = [a.elapsed_time(b) for a, b, _ in ev]
-            out[name] = dict(calls=len(ev), avg_ms=sum(ms) / len(ms), units_per_call=sum(u for _, _, u in ev) / len(ev))
+            us = [u if isinstance(u, tuple) else (u,) for _, _, u in ev]
+            tot = tuple(sum(col) for col in zip(*us))
+            out[name] = dict(calls=len(ev), total_ms=sum(ms), avg_ms=sum(ms) / len(ms),
+                             units_total=tot, units_per_call=tuple(t / len(ev) for t in tot))
         return out
 
     def reset(self):

@@ -170,7 +170,10 @@ def conv1d_cl_raw(x, w, bias=None, bias_b=None, res=None, mg_src=None, out=None,
     import ctypes
     e0 = _lib.timer.start("vits_conv1d_cl")
     rc = _lib.lib().vits_conv1d_cl(ctypes.addressof(d), _lib.stream_ptr())
-    _lib.timer.stop("vits_conv1d_cl", e0, 2.0 * b * t_out * c_out * c_in * k)       # units = FLOP
+    if e0 is not None:                                         # units = (FLOP, algorithmic bytes: x + y + w read/written once)
+        es = x.element_size()
+        _lib.timer.stop("vits_conv1d_cl", e0, (2.0 * b * t_out * c_out * c_in * k,
+                                                es * (b * t * c_in + b * t_out * out.size(2) + k * c_out * c_in + (0 if res is None else res.numel()))))
     _lib.check(rc, "vits_conv1d_cl")
     return out
 
@@ -209,6 +212,9 @@ def conv1d_cl_wgrad_raw(x, dy, k, lengths=None, dil=1, pad=0, stride=1, in_slope
     import ctypes
     e0 = _lib.timer.start("vits_conv1d_cl_wgrad")
     rc = L.vits_conv1d_cl_wgrad(ctypes.addressof(d), _lib.stream_ptr())
-    _lib.timer.stop("vits_conv1d_cl_wgrad", e0, 2.0 * b * t_out * c_out * c_in * k)
+    if e0 is not None:
+        es = x.element_size()
+        _lib.timer.stop("vits_conv1d_cl_wgrad", e0, (2.0 * b * t_out * c_out * c_in * k,
+                                                      es * (b * t * c_in + b * t_out * c_out) + 4.0 * k * c_out * c_in))
     _lib.check(rc, "vits_conv1d_cl_wgrad")
     return out

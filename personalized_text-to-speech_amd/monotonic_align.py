@@ -30,7 +30,7 @@ def maximum_path_lengths(neg_cent, t_ys, t_xs, out_dtype=None, status=None):
     rc = _lib.lib().vits_mas_f32(nc.data_ptr(), path.data_ptr(), kernel_dtype if kernel_dtype is not None else 0,
                                  t_ys.data_ptr(), t_xs.data_ptr(), b, t_t, t_s,
                                  status.data_ptr() if status is not None else None, _lib.stream_ptr())
-    _lib.timer.stop("vits_mas_f32", e0, b * t_t * t_s)       # units = DP cells
+    _lib.timer.stop("vits_mas_f32", e0, (b * t_t * t_s, 8.0 * b * t_t * t_s))       # units = (DP cells, bytes: 4 read + 4 written per cell)
     _lib.check(rc, "vits_mas_f32")
     return path if kernel_dtype is not None else path.to(out_dtype)
 
