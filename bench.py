@@ -158,8 +158,13 @@ def main():
         if per_kernel:
             dom = max(per_kernel, key=lambda k: per_kernel[k]["ms_per_step"])        # dominant hand-written kernel
             d, sm = per_kernel[dom], summ[dom]
+            traffic = None                       # HBM bytes per launch from the committed PMC passes (not collectable in-process)
+            try:
+                traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[dom]["bytes_per_launch"]
+            except Exception:
+                pass
             roof = dict(kernel=dom, bound="hbm", achieved=d["algorithmic_GBps"], peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=d["algorithmic_GBps"] / HBM_PEAK_GBS, traffic=None, avg_launch_us=d["avg_launch_us"],
+                        frac=d["algorithmic_GBps"] / HBM_PEAK_GBS, traffic=traffic, avg_launch_us=d["avg_launch_us"],
                         bytes_per_launch=sm["units_per_call"][1], launches_per_step=d["launches_per_step"],
                         mfma_TFLOPs=d["TFLOPs"], mfma_peak_TFLOPs=(2500.0 if not args.fp32 else 157.3),
                         note="algorithmic bytes = x + y (+res) + w once per launch, summed over the launches of one step, / their summed HIP-event time; "

@@ -17,15 +17,15 @@ from . import _lib
 from . import monotonic_align as _ma
 
 BACKENDS = {
-    "maximum_path": "hip",
+    "maximum_path (alignment DP)": "hip",
     "decoder (Generator: conv_pre, ups, ResBlocks, conv_post; fwd+bwd)": "hip",
     "posterior encoder + flow (1x1 pre/post/proj, gated WN stacks; fwd+bwd)": "hip",
-    "conv1d (text encoder, duration predictor, discriminators)": "rocm",
-    "weight_norm": "rocm",
-    "layer_norm_c": "rocm",
-    "rel_attention": "rocm",
-    "rq_spline": "rocm",
-    "stft_magnitude": "rocm",
+    "stochastic duration predictor (DDSConv: dwconv, LayerNorm+GELU, 1x1; spline; fwd+bwd)": "hip",
+    "weight preparation (weight-norm, layouts, dtype; fwd+bwd)": "hip",
+    "text encoder (rel. attention, FFN, LayerNorm)": "rocm",
+    "stft / mel": "rocm",
+    "discriminators (MIOpen, as BASELINE.json allows)": "rocm",
+    "AdamW (torch fused multi-tensor)": "rocm",
 }
 
 
