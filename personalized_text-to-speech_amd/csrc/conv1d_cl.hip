@@ -16,9 +16,12 @@
 // because a 16-byte fragment at byte offset 32*m + 16*h of a 128-byte channel chunk means
 // "elements k = 8h..8h+7 of MFMA m" for bf16 and "k = h of MFMAs 4m..4m+3" for f32.
 //
-// Workgroup = 4 waves = 128 time rows x (32*NT) output channels; per 128-byte input-channel chunk
-// the X rows (with halo, input activation and row mask applied once) and a group of taps of W are
-// staged in LDS with a 16-byte row pad (pitch 144 B: conflict-free ds_read_b128).
+// Workgroup = 4 waves arranged WM (time) x WN (channels), each wave 32 rows x 32*NT output channels;
+// the tile is chosen per launch so that small layers still put >= 2 workgroups on every CU.  Per 128-byte
+// input-channel chunk the X rows (with halo, input activation and row mask applied once) and a group of
+// taps of W are staged in LDS with a 16-byte row pad (pitch 144 B: conflict-free ds_read_b128); the
+// global loads of the NEXT stage are issued into registers before the current stage's MFMAs and written
+// to LDS after them (register-prefetch software pipeline, cdna_hip_programming.md T14).
 //
 // Fused epilogue (flags): + bias[co] + bias_b[b][co] (speaker conditioning) + residual, * scale,
 // * leaky-relu'(src) (chain rule of a fused input activation, for the data-gradient call),
@@ -31,7 +34,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int TM = 128;            // time rows per workgroup
+
 constexpr int ROWB = 128;          // bytes of input channels staged per chunk
 constexpr int PITCH = ROWB + 16;   // LDS row pitch
 constexpr int kThreads = 256;
@@ -66,25 +69,33 @@ __device__ __forceinline__ u32x4 lrelu_vec(u32x4 raw, float slope) {
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
 
-template <typename T, int NT>
+constexpr int XV_MAX = 6;     // 16-byte vectors of the X tile a thread may hold in flight (xrows*8 <= 256*XV_MAX)
+constexpr int WV_MAX = 9;     // ... of the W slab (G*TN*8 <= 256*WV_MAX)
+
+// WM waves along time x WN = 4/WM waves along output channels; each wave owns 32 rows x 32*NT columns.
+template <typename T, int NT, int WM>
 __global__ __launch_bounds__(kThreads) void conv1d_cl_kernel(ConvArgs args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const vits_conv_desc& a = args.d;
   constexpr int V = Elem<T>::VEC;
   constexpr int KC = Elem<T>::KC;
-  constexpr int TN = 32 * NT;
+  constexpr int WN = 4 / WM;
+  constexpr int TMW = 32 * WM;            // time rows per workgroup
+  constexpr int TNW = 32 * NT;            // columns per wave
+  constexpr int TN = TNW * WN;            // columns per workgroup
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
+  const int wm = wave % WM, wn = wave / WM;
   const int r = lane & 31, h = lane >> 5;
-  const int t0 = blockIdx.x * TM;
+  const int t0 = blockIdx.x * TMW;
   const int b = blockIdx.z;
   const int Tout = args.Tout;
   const bool gate = (a.flags & VITS_CONV_GATE) != 0;
-  // output-channel origin of this workgroup: in GATE mode the NT tiles are split in two halves
-  // (columns co0.. of the tanh half and co0 + gate_h.. of the sigmoid half).
+  // output-channel origin of this workgroup: in GATE mode every wave's NT tiles are split in two halves
+  // (columns c.. of the tanh half and c + gate_h.. of the sigmoid half), so a workgroup covers TN/2 gate channels.
   const int co0 = blockIdx.y * (gate ? TN / 2 : TN);
-  const int xrows = (TM - 1) * a.stride + (a.k - 1) * a.dil + 1;
+  const int xrows = (TMW - 1) * a.stride + (a.k - 1) * a.dil + 1;
   unsigned char* ldsX = smem;
   unsigned char* ldsW = smem + (size_t)xrows * PITCH;
 
@@ -93,73 +104,129 @@ __global__ __launch_bounds__(kThreads) void conv1d_cl_kernel(ConvArgs args) {
   const int len = (a.lengths != nullptr) ? a.lengths[b] : a.t;
   const int t_in_hi = (a.flags & VITS_CONV_MASK_IN) ? (len < a.t ? len : a.t) : a.t;
 
+  // output channel of LDS column `col` (0 <= col < TN) of this workgroup, or -1
+  auto col_to_co = [&](int col) -> int {
+    const int w_ = col / TNW, n = (col % TNW) / 32, c = col % 32;
+    if (!gate) { const int co = co0 + col; return co < a.c_out ? co : -1; }
+    const int half = n / (NT / 2 > 0 ? NT / 2 : 1), sub = n % (NT / 2 > 0 ? NT / 2 : 1);
+    const int g = co0 + (w_ * (NT / 2) + sub) * 32 + c;            // gate channel
+    return g < a.gate_h ? g + half * a.gate_h : -1;
+  };
+
   f32x16 acc[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
 
-  for (int ci0 = 0; ci0 < a.c_in; ci0 += KC) {
-    for (int tg = 0; tg < a.k; tg += args.G) {
-      __syncthreads();                       // previous compute finished with ldsW (and ldsX)
-      if (tg == 0) {
-        // ---- stage X rows [t0*stride - pad, ... + xrows) x channels [ci0, ci0 + KC)
-        for (int idx = tid; idx < xrows * 8; idx += kThreads) {
-          const int row = idx >> 3, ch = idx & 7;
-          const int t = t0 * a.stride - a.pad + row;
-          const int ci = ci0 + ch * V;
-          u32x4 v = {0u, 0u, 0u, 0u};
-          if (t >= 0 && t < t_in_hi && ci < a.c_in) {
-            v = *reinterpret_cast<const u32x4*>(X + (size_t)t * a.ldx + ci);
-            if (a.in_slope != 1.0f) v = lrelu_vec<T>(v, a.in_slope);
+  const int n_groups = (a.k + args.G - 1) / args.G;
+  const int n_chunks = (a.c_in + KC - 1) / KC;
+  const int n_stages = n_groups * n_chunks;
+  const int xvec = xrows * 8;
+  const bool x_in_regs = xvec <= kThreads * XV_MAX;        // else: stage X synchronously (long strided tiles)
+
+  u32x4 xr[XV_MAX], wr[WV_MAX];
+  auto load_x = [&](int ci0) {
+#pragma unroll
+    for (int i = 0; i < XV_MAX; ++i) {
+      const int idx = tid + i * kThreads;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (idx < xvec) {
+        const int row = idx >> 3, ch = idx & 7;
+        const int t = t0 * a.stride - a.pad + row, ci = ci0 + ch * V;
+        if (t >= 0 && t < t_in_hi && ci < a.c_in) {
+          v = *reinterpret_cast<const u32x4*>(X + (size_t)t * a.ldx + ci);
+          if (a.in_slope != 1.0f) v = lrelu_vec<T>(v, a.in_slope);
+        }
+      }
+      xr[i] = v;
+    }
+  };
+  auto store_x = [&]() {
+#pragma unroll
+    for (int i = 0; i < XV_MAX; ++i) {
+      const int idx = tid + i * kThreads;
+      if (idx < xvec) *reinterpret_cast<u32x4*>(ldsX + (idx >> 3) * PITCH + (idx & 7) * 16) = xr[i];
+    }
+  };
+  auto stage_x_direct = [&](int ci0) {
+    for (int idx = tid; idx < xvec; idx += kThreads) {
+      const int row = idx >> 3, ch = idx & 7;
+      const int t = t0 * a.stride - a.pad + row, ci = ci0 + ch * V;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (t >= 0 && t < t_in_hi && ci < a.c_in) {
+        v = *reinterpret_cast<const u32x4*>(X + (size_t)t * a.ldx + ci);
+        if (a.in_slope != 1.0f) v = lrelu_vec<T>(v, a.in_slope);
+      }
+      *reinterpret_cast<u32x4*>(ldsX + row * PITCH + ch * 16) = v;
+    }
+  };
+  auto load_w = [&](int ci0, int tg) {
+    const int ntap = (a.k - tg < args.G) ? (a.k - tg) : args.G;
+#pragma unroll
+    for (int i = 0; i < WV_MAX; ++i) {
+      const int idx = tid + i * kThreads;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (idx < ntap * TN * 8) {
+        const int ch = idx & 7, col = (idx >> 3) % TN, tl = (idx >> 3) / TN;
+        const int co = col_to_co(col), ci = ci0 + ch * V;
+        if (co >= 0 && ci < a.c_in) v = *reinterpret_cast<const u32x4*>(W + ((size_t)(tg + tl) * a.c_out + co) * a.c_in + ci);
+      }
+      wr[i] = v;
+    }
+  };
+  auto store_w = [&](int tg) {
+    const int ntap = (a.k - tg < args.G) ? (a.k - tg) : args.G;
+#pragma unroll
+    for (int i = 0; i < WV_MAX; ++i) {
+      const int idx = tid + i * kThreads;
+      if (idx < ntap * TN * 8) *reinterpret_cast<u32x4*>(ldsW + (idx >> 3) * PITCH + (idx & 7) * 16) = wr[i];
+    }
+  };
+
+  // ---- software pipeline: the global loads of stage s+1 are in flight while stage s is multiplied
+  load_w(0, 0);
+  if (x_in_regs) { load_x(0); store_x(); } else stage_x_direct(0);
+  store_w(0);
+  __syncthreads();
+  for (int s = 0; s < n_stages; ++s) {
+    const int tg = (s % n_groups) * args.G;
+    const int nxt = s + 1;
+    const int nci0 = (nxt / n_groups) * KC, ntg = (nxt % n_groups) * args.G;
+    const bool has_next = nxt < n_stages, new_chunk = has_next && (nxt % n_groups == 0);
+    if (has_next) {
+      load_w(nci0, ntg);
+      if (new_chunk && x_in_regs) load_x(nci0);
+    }
+    const int ntap = (a.k - tg < args.G) ? (a.k - tg) : args.G;
+    for (int tl = 0; tl < ntap; ++tl) {
+      const unsigned char* xa = ldsX + ((wm * 32 + r) * a.stride + (tg + tl) * a.dil) * PITCH + 16 * h;
+      const unsigned char* wb = ldsW + (tl * TN + wn * TNW + r) * PITCH + 16 * h;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const u32x4 av = *reinterpret_cast<const u32x4*>(xa + 32 * m);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const u32x4 bv = *reinterpret_cast<const u32x4*>(wb + n * 32 * PITCH + 32 * m);
+          if constexpr (sizeof(T) == 2) {
+            union { u32x4 u; bf16x8 v; } ua, ub;
+            ua.u = av; ub.u = bv;
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.v, ub.v, acc[n], 0, 0, 0);
+          } else {
+            union { u32x4 u; float f[4]; } ua, ub;
+            ua.u = av; ub.u = bv;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua.f[j], ub.f[j], acc[n], 0, 0, 0);
           }
-          *reinterpret_cast<u32x4*>(ldsX + row * PITCH + ch * 16) = v;
         }
       }
-      // ---- stage W[tg .. tg+G)[this workgroup's TN output channels][ci0 .. ci0+KC)
-      const int ntap = (a.k - tg < args.G) ? (a.k - tg) : args.G;
-      for (int idx = tid; idx < ntap * TN * 8; idx += kThreads) {
-        const int ch = idx & 7;
-        const int col = (idx >> 3) % TN;
-        const int tl = (idx >> 3) / TN;
-        int co = co0 + col;
-        bool ok = co < a.c_out;
-        if (gate) {
-          const int half = col / (TN / 2), sub = col % (TN / 2);
-          co = co0 + sub + half * a.gate_h;
-          ok = (co0 + sub) < a.gate_h;
-        }
-        const int ci = ci0 + ch * V;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (ok && ci < a.c_in)
-          v = *reinterpret_cast<const u32x4*>(W + ((size_t)(tg + tl) * a.c_out + co) * a.c_in + ci);
-        *reinterpret_cast<u32x4*>(ldsW + (tl * TN + col) * PITCH + ch * 16) = v;
-      }
+    }
+    if (has_next) {
+      __syncthreads();                       // every wave is done reading this stage's LDS
+      store_w(ntg);
+      if (new_chunk) { if (x_in_regs) store_x(); else stage_x_direct(nci0); }
       __syncthreads();
-      // ---- MFMA over the staged taps and the chunk's 4 macro-steps
-      for (int tl = 0; tl < ntap; ++tl) {
-        const unsigned char* xa = ldsX + ((wave * 32 + r) * a.stride + (tg + tl) * a.dil) * PITCH + 16 * h;
-        const unsigned char* wb = ldsW + (tl * TN + r) * PITCH + 16 * h;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const u32x4 av = *reinterpret_cast<const u32x4*>(xa + 32 * m);
-#pragma unroll
-          for (int n = 0; n < NT; ++n) {
-            const u32x4 bv = *reinterpret_cast<const u32x4*>(wb + n * 32 * PITCH + 32 * m);
-            if constexpr (sizeof(T) == 2) {
-              union { u32x4 u; bf16x8 v; } ua, ub;
-              ua.u = av; ub.u = bv;
-              acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.v, ub.v, acc[n], 0, 0, 0);
-            } else {
-              union { u32x4 u; float f[4]; } ua, ub;
-              ua.u = av; ub.u = bv;
-#pragma unroll
-              for (int j = 0; j < 4; ++j)
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua.f[j], ub.f[j], acc[n], 0, 0, 0);
-            }
-          }
-        }
-      }
     }
   }
 
@@ -175,14 +242,14 @@ __global__ __launch_bounds__(kThreads) void conv1d_cl_kernel(ConvArgs args) {
       T* Y2 = a.y2 ? static_cast<T*>(a.y2) + (size_t)b * Tout * a.ldy2 : nullptr;
 #pragma unroll
       for (int n = 0; n < NT / 2; ++n) {
-        const int co = co0 + n * 32 + r;
+        const int co = co0 + (wn * (NT / 2) + n) * 32 + r;
         if (co >= a.gate_h) continue;
         float ba = 0.f, bb = 0.f;
         if (a.bias) { ba += a.bias[co]; bb += a.bias[co + a.gate_h]; }
         if (a.bias_b) { ba += a.bias_b[(size_t)b * a.c_out + co]; bb += a.bias_b[(size_t)b * a.c_out + co + a.gate_h]; }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const int t = t0 + wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          const int t = t0 + wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
           if (t >= Tout) continue;
           const float va = acc[n][i] + ba, vb = acc[n + NT / 2][i] + bb;
           if (Y2) {
@@ -198,14 +265,14 @@ __global__ __launch_bounds__(kThreads) void conv1d_cl_kernel(ConvArgs args) {
 
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
-    const int co = co0 + n * 32 + r;
+    const int co = co0 + (wn * NT + n) * 32 + r;
     if (co >= a.c_out) continue;
     float bsum = 0.f;
     if (a.bias) bsum += a.bias[co];
     if (a.bias_b) bsum += a.bias_b[(size_t)b * a.c_out + co];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const int t = t0 + wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+      const int t = t0 + wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
       if (t >= Tout) continue;
       const size_t o = (size_t)t * a.ldy + co;
       float v = acc[n][i] + bsum;
@@ -230,35 +297,46 @@ __global__ __launch_bounds__(kThreads) void conv1d_cl_kernel(ConvArgs args) {
   }
 }
 
-template <typename T, int NT>
+template <typename T, int NT, int WM>
 int launch_conv(const vits_conv_desc& d, int t_out, hipStream_t s) {
   ConvArgs args{d, t_out, 1};
-  const int TN = 32 * NT;
-  const int xrows = (TM - 1) * d.stride + (d.k - 1) * d.dil + 1;
-  int G = (40 * 1024) / (TN * PITCH);            // taps per W stage: keep the W slab under ~40 KB
+  constexpr int WN = 4 / WM, TMW = 32 * WM, TN = 32 * NT * WN;
+  const int xrows = (TMW - 1) * d.stride + (d.k - 1) * d.dil + 1;
+  int G = (kThreads * WV_MAX) / (TN * 8);        // taps per W stage: what one prefetch round can hold (<= 41 KB)
   if (G < 1) G = 1;
   if (G > d.k) G = d.k;
   args.G = G;
   const size_t lds = (size_t)xrows * PITCH + (size_t)G * TN * PITCH;
   if (lds > (size_t)vits::kLdsBytesMax) return VITS_E_UNSUPPORTED;
-  auto kern = conv1d_cl_kernel<T, NT>;
+  auto kern = conv1d_cl_kernel<T, NT, WM>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return vits::note_hip_error(e, "vits_conv1d_cl/attr");
   }
   const bool gate = (d.flags & VITS_CONV_GATE) != 0;
   const int cols = gate ? d.gate_h : d.c_out;
-  dim3 grid(vits::ceil_div(t_out, TM), vits::ceil_div(cols, gate ? TN / 2 : TN), d.b);
+  dim3 grid(vits::ceil_div(t_out, TMW), vits::ceil_div(cols, gate ? TN / 2 : TN), d.b);
   hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, s, args);
   return vits::check_launch("vits_conv1d_cl");
 }
 
+// Tile choice: the largest tile that still gives the chip >= 2 workgroups per CU, else the smallest.
+// (time rows x channels): 128x128, 128x64, 64x128(2x2 waves), 64x64, 128x32
 template <typename T>
-int dispatch_nt(const vits_conv_desc& d, int t_out, hipStream_t s) {
-  if (d.flags & VITS_CONV_GATE) return launch_conv<T, 4>(d, t_out, s);
-  if (d.c_out > 64) return launch_conv<T, 4>(d, t_out, s);
-  if (d.c_out > 32) return launch_conv<T, 2>(d, t_out, s);
-  return launch_conv<T, 1>(d, t_out, s);
+int dispatch_tile(const vits_conv_desc& d, int t_out, hipStream_t s) {
+  const bool gate = (d.flags & VITS_CONV_GATE) != 0;
+  const int cols = gate ? 2 * d.gate_h : d.c_out;
+  auto wgs = [&](int tm, int tn) { return (long)vits::ceil_div(t_out, tm) * vits::ceil_div(cols, tn) * d.b; };
+  const long want = 2 * 256;
+  if (gate) {                                    // needs an even number of tiles per wave
+    if (wgs(128, 128) >= want || cols <= 64) return launch_conv<T, 4, 4>(d, t_out, s);
+    return launch_conv<T, 2, 2>(d, t_out, s);    // 64 rows x (2 waves x 64 columns)
+  }
+  if (cols > 64 && wgs(128, 128) >= want) return launch_conv<T, 4, 4>(d, t_out, s);
+  if (cols > 64 && wgs(64, 128) >= want) return launch_conv<T, 2, 2>(d, t_out, s);
+  if (cols > 32 && wgs(128, 64) >= want) return launch_conv<T, 2, 4>(d, t_out, s);
+  if (cols > 32) return launch_conv<T, 1, 2>(d, t_out, s);           // 64 x 64
+  return launch_conv<T, 1, 4>(d, t_out, s);                           // 128 x 32
 }
 
 }  // namespace
@@ -282,11 +360,11 @@ extern "C" int vits_conv1d_cl(const vits_conv_desc* desc, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (d.dtype == VITS_DT_BF16) {
     if (d.c_in % 8 != 0 || d.ldx % 8 != 0) return VITS_E_UNSUPPORTED;
-    return dispatch_nt<__bf16>(d, t_out, s);
+    return dispatch_tile<__bf16>(d, t_out, s);
   }
   if (d.dtype == VITS_DT_F32) {
     if (d.c_in % 4 != 0 || d.ldx % 4 != 0) return VITS_E_UNSUPPORTED;
-    return dispatch_nt<float>(d, t_out, s);
+    return dispatch_tile<float>(d, t_out, s);
   }
   return VITS_E_UNSUPPORTED;
 }
