@@ -126,7 +126,7 @@ int vits_conv1d_cl(const vits_conv_desc* desc, void* stream);
 /* Weight gradient of vits_conv1d_cl (same x, lengths, in_slope, MASK flags as the forward call):
  *   dw[tap][co][ci] (+)= sum_{b,t} dy[b][t][co] * lrelu_{in_slope}(x[b][t + tap*dil - pad][ci])
  * Replaces the weight half of autograd's conv1d backward for the layers listed above.
- *   dy [b][t_out][c_out] (dtype of x);  dw float32 [k][c_out][c_in];  k in {1,3,5,7,11};
+ *   dy [b][t_out][c_out] (dtype of x);  dw float32 [k][c_out][c_in];  any k;
  *   workspace: device scratch of at least vits_conv1d_cl_wgrad_workspace(...) bytes (per-split fp32
  *   slabs, summed in a fixed order: results are bitwise reproducible);
  *   flags: VITS_CONV_MASK_IN (x rows >= lengths[b] are zero), VITS_CONV_MASK_OUT (dy rows >=

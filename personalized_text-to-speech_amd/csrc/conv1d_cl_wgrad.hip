@@ -11,8 +11,8 @@
 //          aligned, and it is);
 //   f32  : v_mfma_f32_32x32x2_f32 takes one k per lane, so lane (i, h) simply reads row 2s+h,
 //          column i: a conflict-free ds_read_b32.
-// Workgroup = 4 waves = 64 co x 64 ci x all taps (wave (i,j) owns the 32x32 block (i,j) and one
-// accumulator per tap).  The (b, t) reduction is split over blockIdx.x; every split writes its own
+// Workgroup = 4 waves = 64 co x 64 ci x a group of <= 4 taps (wave (i,j) owns the 32x32 block (i,j) and one
+// accumulator per tap); the next chunk's tiles are prefetched into registers during the MFMAs.  The (b, t) reduction is split over blockIdx.x; every split writes its own
 // fp32 slab and a second kernel sums the slabs in a fixed order (bitwise reproducible — no float
 // atomics, cdna_hip_programming.md Guideline 12).
 #include "common.h"
@@ -59,6 +59,12 @@ template <typename T> struct Pitch;
 template <> struct Pitch<__bf16> { static constexpr int value = CT * 2 + 64; };   // 192 B: tr-reads conflict-free
 template <> struct Pitch<float> { static constexpr int value = CT * 4 + 16; };
 
+constexpr int DV_MAX = 8;      // 16-byte vectors of the dY tile per thread (TK*VPR <= 256*DV_MAX)
+constexpr int XV_MAX = 10;     // ... of the X tile (xrows*VPR <= 256*XV_MAX, else staged synchronously)
+
+// One workgroup = one 64(co) x 64(ci) tile x one GROUP of at most KT taps x one split of the (b,t) reduction.
+// Splitting the taps over workgroups multiplies the parallelism of large-k layers without any extra slab
+// traffic (the tiles of x and dy are re-read from L2), and keeps the accumulators at KT*16 registers.
 template <typename T, int KT>
 __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -68,10 +74,15 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wi = wave >> 1, wj = wave & 1;
   const int r = lane & 31, h = lane >> 5;
-  const int co0 = blockIdx.y * CT, ci0 = blockIdx.z * CT;
-  const int xrows = (TK - 1) * a.stride + (KT - 1) * a.dil + 1;
+  const int n_ci_tiles = (a.Cin + CT - 1) / CT;
+  const int co0 = blockIdx.y * CT, ci0 = (blockIdx.z % n_ci_tiles) * CT;
+  const int tap0 = (blockIdx.z / n_ci_tiles) * KT;
+  const int ntap = (a.K - tap0 < KT) ? (a.K - tap0) : KT;
+  const int xrows = (TK - 1) * a.stride + (ntap - 1) * a.dil + 1;
   unsigned char* ldsD = smem;                               // [TK][CT] of dY
-  unsigned char* ldsX = smem + (size_t)TK * PITCH;          // [xrows][CT] of act(X)
+  unsigned char* ldsX = smem + (size_t)TK * PITCH;          // [xrows][CT] of act(X), first row = tap0's
+  const int dvec = TK * VPR, xvec = xrows * VPR;
+  const bool x_in_regs = xvec <= kThreads * XV_MAX;
 
   f32x16 acc[KT];
 #pragma unroll
@@ -79,34 +90,76 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
 
-  const int n_chunks = a.B * a.chunks_per_item;
-  for (int ch = blockIdx.x; ch < n_chunks; ch += a.S) {
-    const int b = ch / a.chunks_per_item;
-    const int t0 = (ch % a.chunks_per_item) * TK;
+  u32x4 dr[DV_MAX], xr[XV_MAX];
+  auto chunk_info = [&](int ch, int& b, int& t0, int& t_out_hi, int& t_in_hi) {
+    b = ch / a.chunks_per_item;
+    t0 = (ch % a.chunks_per_item) * TK;
     const int len = a.lengths ? a.lengths[b] : a.T;
-    const int t_out_hi = (a.flags & VITS_CONV_MASK_OUT) ? (len < a.Tout ? len : a.Tout) : a.Tout;
-    const int t_in_hi = (a.flags & VITS_CONV_MASK_IN) ? (len < a.T ? len : a.T) : a.T;
+    t_out_hi = (a.flags & VITS_CONV_MASK_OUT) ? (len < a.Tout ? len : a.Tout) : a.Tout;
+    t_in_hi = (a.flags & VITS_CONV_MASK_IN) ? (len < a.T ? len : a.T) : a.T;
+  };
+  auto load_x_vec = [&](const T* X, int idx, int t0, int t_in_hi) -> u32x4 {
+    const int row = idx / VPR, vc = idx % VPR;
+    const int t = t0 * a.stride - a.pad + tap0 * a.dil + row, ci = ci0 + vc * V;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (t >= 0 && t < t_in_hi && ci < a.Cin) {
+      v = *reinterpret_cast<const u32x4*>(X + (size_t)t * a.ldx + ci);
+      if (a.in_slope != 1.0f) v = lrelu_vec<T>(v, a.in_slope);
+    }
+    return v;
+  };
+  auto load_chunk = [&](int ch) {
+    int b, t0, t_out_hi, t_in_hi;
+    chunk_info(ch, b, t0, t_out_hi, t_in_hi);
     const T* X = static_cast<const T*>(a.x) + (size_t)b * a.T * a.ldx;
     const T* DY = static_cast<const T*>(a.dy) + (size_t)b * a.Tout * a.lddy;
-    __syncthreads();
-    for (int idx = tid; idx < TK * VPR; idx += kThreads) {
-      const int row = idx / VPR, vc = idx % VPR;
-      const int t = t0 + row, co = co0 + vc * V;
+#pragma unroll
+    for (int i = 0; i < DV_MAX; ++i) {
+      const int idx = tid + i * kThreads;
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (t < t_out_hi && co < a.Cout) v = *reinterpret_cast<const u32x4*>(DY + (size_t)t * a.lddy + co);
-      *reinterpret_cast<u32x4*>(ldsD + row * PITCH + vc * 16) = v;
-    }
-    for (int idx = tid; idx < xrows * VPR; idx += kThreads) {
-      const int row = idx / VPR, vc = idx % VPR;
-      const int t = t0 * a.stride - a.pad + row, ci = ci0 + vc * V;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (t >= 0 && t < t_in_hi && ci < a.Cin) {
-        v = *reinterpret_cast<const u32x4*>(X + (size_t)t * a.ldx + ci);
-        if (a.in_slope != 1.0f) v = lrelu_vec<T>(v, a.in_slope);
+      if (idx < dvec) {
+        const int row = idx / VPR, vc = idx % VPR;
+        const int t = t0 + row, co = co0 + vc * V;
+        if (t < t_out_hi && co < a.Cout) v = *reinterpret_cast<const u32x4*>(DY + (size_t)t * a.lddy + co);
       }
-      *reinterpret_cast<u32x4*>(ldsX + row * PITCH + vc * 16) = v;
+      dr[i] = v;
     }
-    __syncthreads();
+    if (x_in_regs) {
+#pragma unroll
+      for (int i = 0; i < XV_MAX; ++i) {
+        const int idx = tid + i * kThreads;
+        xr[i] = (idx < xvec) ? load_x_vec(X, idx, t0, t_in_hi) : u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+  };
+  auto store_chunk = [&](int ch) {
+#pragma unroll
+    for (int i = 0; i < DV_MAX; ++i) {
+      const int idx = tid + i * kThreads;
+      if (idx < dvec) *reinterpret_cast<u32x4*>(ldsD + (idx / VPR) * PITCH + (idx % VPR) * 16) = dr[i];
+    }
+    if (x_in_regs) {
+#pragma unroll
+      for (int i = 0; i < XV_MAX; ++i) {
+        const int idx = tid + i * kThreads;
+        if (idx < xvec) *reinterpret_cast<u32x4*>(ldsX + (idx / VPR) * PITCH + (idx % VPR) * 16) = xr[i];
+      }
+    } else {
+      int b, t0, t_out_hi, t_in_hi;
+      chunk_info(ch, b, t0, t_out_hi, t_in_hi);
+      const T* X = static_cast<const T*>(a.x) + (size_t)b * a.T * a.ldx;
+      for (int idx = tid; idx < xvec; idx += kThreads)
+        *reinterpret_cast<u32x4*>(ldsX + (idx / VPR) * PITCH + (idx % VPR) * 16) = load_x_vec(X, idx, t0, t_in_hi);
+    }
+  };
+
+  const int n_chunks = a.B * a.chunks_per_item;
+  int ch = blockIdx.x;
+  if (ch < n_chunks) { load_chunk(ch); store_chunk(ch); }
+  __syncthreads();
+  for (; ch < n_chunks; ch += a.S) {
+    const int nxt = ch + a.S;
+    if (nxt < n_chunks) load_chunk(nxt);                  // in flight during this chunk's MFMAs
 
     if constexpr (sizeof(T) == 2) {
       // transposing reads: within a 16-lane group, lane 4q+p addresses row q, columns 4p..4p+3 and
@@ -127,14 +180,16 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
         }
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
-          union { s16x4 half[2]; bf16x8 v; } fb;
+          if (k < ntap) {
+            union { s16x4 half[2]; bf16x8 v; } fb;
 #pragma unroll
-          for (int rd = 0; rd < 2; ++rd) {
-            auto pb = reinterpret_cast<__attribute__((address_space(3))) s16x4*>(
-                (__attribute__((address_space(3))) unsigned char*)ldsX + ((16 * s + rowk + 4 * rd) * a.stride + k * a.dil) * PITCH + colB);
-            fb.half[rd] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(pb);
+            for (int rd = 0; rd < 2; ++rd) {
+              auto pb = reinterpret_cast<__attribute__((address_space(3))) s16x4*>(
+                  (__attribute__((address_space(3))) unsigned char*)ldsX + ((16 * s + rowk + 4 * rd) * a.stride + k * a.dil) * PITCH + colB);
+              fb.half[rd] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(pb);
+            }
+            acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, fb.v, acc[k], 0, 0, 0);
           }
-          acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, fb.v, acc[k], 0, 0, 0);
         }
       }
     } else {
@@ -146,23 +201,32 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
         const float av = dA[(2 * s + h) * PF];
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
-          const float bv = xB[((2 * s + h) * a.stride + k * a.dil) * PF];
-          acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[k], 0, 0, 0);
+          if (k < ntap) {
+            const float bv = xB[((2 * s + h) * a.stride + k * a.dil) * PF];
+            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[k], 0, 0, 0);
+          }
         }
       }
+    }
+    if (nxt < n_chunks) {
+      __syncthreads();
+      store_chunk(nxt);
+      __syncthreads();
     }
   }
 
   // slab of this split: partial[split][tap][co][ci]
-  float* P = a.partial + (size_t)blockIdx.x * KT * a.Cout * a.Cin;
+  float* P = a.partial + (size_t)blockIdx.x * a.K * a.Cout * a.Cin;
   const int ci = ci0 + wj * 32 + r;
   if (ci < a.Cin) {
 #pragma unroll
     for (int k = 0; k < KT; ++k)
+      if (k < ntap) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int co = co0 + wi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        if (co < a.Cout) P[((size_t)k * a.Cout + co) * a.Cin + ci] = acc[k][i];
+        for (int i = 0; i < 16; ++i) {
+          const int co = co0 + wi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          if (co < a.Cout) P[((size_t)(tap0 + k) * a.Cout + co) * a.Cin + ci] = acc[k][i];
+        }
       }
   }
 }
@@ -179,15 +243,18 @@ __global__ void reduce_slabs(const float* __restrict__ partial, float* __restric
   reinterpret_cast<float4*>(dw)[i] = acc;
 }
 
-// Number of (b,t)-reduction splits: enough workgroups to fill the chip, but never more slab traffic
-// than ~4x the reads of x and dy themselves (each split writes and re-reads one full dW).
+int taps_per_group(int k) { return k <= 4 ? k : (k <= 8 ? (k + 1) / 2 : 4); }
+
+// Number of (b,t)-reduction splits: enough workgroups to fill the chip (together with the tile and tap-group
+// dimensions), but never more slab traffic than ~2x the reads of x and dy (each split writes and re-reads one dW).
 int pick_splits(int b, int t_out, int c_in, int c_out, int k) {
-  const int tiles = vits::ceil_div(c_out, CT) * vits::ceil_div(c_in, CT);
+  const int kt = taps_per_group(k);
+  const int groups = vits::ceil_div(c_out, CT) * vits::ceil_div(c_in, CT) * vits::ceil_div(k, kt);
   const int chunks = b * vits::ceil_div(t_out, TK);
-  int s = 512 / tiles;
+  int s = vits::ceil_div(768, groups);
   const double io_elems = (double)b * t_out * (c_in + c_out);
   const double dw_elems = (double)k * c_out * c_in;
-  const int s_traffic = (int)(io_elems / (2.0 * dw_elems)) + 1;       // fp32 slab = 2x a bf16 element
+  const int s_traffic = (int)(io_elems / dw_elems) + 1;
   if (s > s_traffic) s = s_traffic;
   if (s > 64) s = 64;
   if (s > chunks) s = chunks;
@@ -205,20 +272,18 @@ int launch(const WgradArgs& a, hipStream_t s) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return vits::note_hip_error(e, "vits_conv1d_cl_wgrad/attr");
   }
-  dim3 grid(a.S, vits::ceil_div(a.Cout, CT), vits::ceil_div(a.Cin, CT));
+  dim3 grid(a.S, vits::ceil_div(a.Cout, CT), vits::ceil_div(a.Cin, CT) * vits::ceil_div(a.K, KT));
   hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, s, a);
   return vits::check_launch("vits_conv1d_cl_wgrad");
 }
 
 template <typename T>
 int dispatch_k(const WgradArgs& a, hipStream_t s) {
-  switch (a.K) {
+  switch (taps_per_group(a.K)) {
     case 1: return launch<T, 1>(a, s);
+    case 2: return launch<T, 2>(a, s);
     case 3: return launch<T, 3>(a, s);
-    case 5: return launch<T, 5>(a, s);
-    case 7: return launch<T, 7>(a, s);
-    case 11: return launch<T, 11>(a, s);
-    default: return VITS_E_UNSUPPORTED;
+    default: return launch<T, 4>(a, s);
   }
 }
 
