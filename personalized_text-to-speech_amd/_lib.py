@@ -116,6 +116,7 @@ class KernelTimer:
 
     def __init__(self):
         self.enabled = False
+        self.detail = os.environ.get("VITS_TIMER_DETAIL") == "1"     # key events by launch shape too (tools/time_shapes.py)
         self.events = {}          # name -> [(start, end, units)]
 
     def start(self, name):
@@ -126,9 +127,11 @@ class KernelTimer:
         e0.record()
         return e0
 
-    def stop(self, name, e0, units):
+    def stop(self, name, e0, units, shape=None):
         if e0 is None:
             return
+        if self.detail and shape is not None:
+            name = f"{name} {shape}"
         import torch
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()

@@ -26,14 +26,24 @@ class Encoder(nn.Module):
             self.norm_layers_2.append(LayerNorm(hidden_channels))
 
     def forward(self, x, x_mask):
+        """x [b, c, t] (reference layout).  Runs channels-last: q/k/v/o and FFN convolutions on the MFMA
+        kernel (ReLU and masks fused into the second FFN convolution's prologue), post-norm residual
+        LayerNorms on the row kernel; the residual add is fused into the producing convolution when
+        dropout is off (attentions.py:35-47)."""
+        from . import rowops, wn_cl
+        dtype = wn_cl.compute_dtype()
+        lengths = wn_cl.lengths_of(x_mask)
+        m = x_mask.transpose(1, 2)
         attn_mask = x_mask.unsqueeze(2) * x_mask.unsqueeze(-1)
-        x = x * x_mask
+        h = (x * x_mask).transpose(1, 2).to(dtype).contiguous()
+        drop = self.training and self.p_dropout > 0
         for i in range(self.n_layers):
-            y = self.drop(self.attn_layers[i](x, x, attn_mask))
-            x = self.norm_layers_1[i](x + y)
-            y = self.drop(self.ffn_layers[i](x, x_mask))
-            x = self.norm_layers_2[i](x + y)
-        return x * x_mask
+            att, ffn, n1, n2 = self.attn_layers[i], self.ffn_layers[i], self.norm_layers_1[i], self.norm_layers_2[i]
+            y = att.forward_cl(h, attn_mask, lengths, None if drop else h)            # conv_o(attention) (+ h)
+            h = rowops.ln_act(h + self.drop(y) if drop else y, n1.gamma, n1.beta, None, n1.eps, 0)
+            y = ffn.forward_cl(h, lengths, None if drop else h)
+            h = rowops.ln_act(h + self.drop(y) if drop else y, n2.gamma, n2.beta, None, n2.eps, 0)
+        return (h * m.to(dtype)).transpose(1, 2).to(x.dtype)
 
 
 class MultiHeadAttention(nn.Module):
@@ -67,6 +77,16 @@ class MultiHeadAttention(nn.Module):
                                        self.window_size, self.p_dropout, self.training)
         return self.conv_o(x)
 
+    def forward_cl(self, h, attn_mask, lengths, res=None):
+        """h [b, t, c] channels-last -> conv_o(attention(h)) (+ res), 1x1 projections on the MFMA kernel."""
+        from . import wn_cl
+        q = wn_cl.conv_cl(h, wn_cl.weight_of(self.conv_q), self.conv_q.bias)
+        k = wn_cl.conv_cl(h, wn_cl.weight_of(self.conv_k), self.conv_k.bias)
+        v = wn_cl.conv_cl(h, wn_cl.weight_of(self.conv_v), self.conv_v.bias)
+        o, self.attn = K.rel_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), self.emb_rel_k, self.emb_rel_v,
+                                       attn_mask, self.n_heads, self.window_size, self.p_dropout, self.training)
+        return wn_cl.conv_cl(o.transpose(1, 2).contiguous(), wn_cl.weight_of(self.conv_o), self.conv_o.bias, res=res)
+
 
 class FFN(nn.Module):
     def __init__(self, in_channels, out_channels, filter_channels, kernel_size, p_dropout=0.0, activation=None, causal=False):
@@ -86,3 +106,17 @@ class FFN(nn.Module):
         x = self.drop(torch.relu(x))
         x = self.conv_2(x * x_mask)
         return x * x_mask
+
+    def forward_cl(self, h, lengths, res=None):
+        """h [b, t, c] channels-last -> conv_2(relu(conv_1(h * mask)) * mask) * mask (+ res)
+        (attentions.py:277-293): mask-in / ReLU are prologues, mask-out / residual epilogues of the two convolutions."""
+        from . import wn_cl
+        pad = (self.kernel_size - 1) // 2
+        y = wn_cl.conv_cl(h, wn_cl.weight_of(self.conv_1), self.conv_1.bias, lengths, pad=pad, mask_in=True)
+        if self.training and self.p_dropout > 0:
+            y = self.drop(torch.relu(y))
+            y = wn_cl.conv_cl(y, wn_cl.weight_of(self.conv_2), self.conv_2.bias, lengths, pad=pad, mask_in=True, mask_out=True)
+            return y if res is None else y + res
+        if res is not None:     # (conv * mask) + res: res rows beyond the length are zero in the encoder, so masking the sum is exact
+            return wn_cl.conv_cl(y, wn_cl.weight_of(self.conv_2), self.conv_2.bias, lengths, pad=pad, in_slope=0.0, mask_in=True, mask_out=True, res=res)
+        return wn_cl.conv_cl(y, wn_cl.weight_of(self.conv_2), self.conv_2.bias, lengths, pad=pad, in_slope=0.0, mask_in=True, mask_out=True)

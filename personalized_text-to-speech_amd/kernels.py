@@ -173,7 +173,8 @@ def conv1d_cl_raw(x, w, bias=None, bias_b=None, res=None, mg_src=None, out=None,
     if e0 is not None:                                         # units = (FLOP, algorithmic bytes: x + y + w read/written once)
         es = x.element_size()
         _lib.timer.stop("vits_conv1d_cl", e0, (2.0 * b * t_out * c_out * c_in * k,
-                                                es * (b * t * c_in + b * t_out * out.size(2) + k * c_out * c_in + (0 if res is None else res.numel()))))
+                                                es * (b * t * c_in + b * t_out * out.size(2) + k * c_out * c_in + (0 if res is None else res.numel()))),
+                        shape=f"b{b} t{t} ci{c_in} co{c_out} k{k} d{dil} s{stride} f{flags} {str(x.dtype)[6:]}")
     _lib.check(rc, "vits_conv1d_cl")
     return out
 
@@ -215,6 +216,7 @@ def conv1d_cl_wgrad_raw(x, dy, k, lengths=None, dil=1, pad=0, stride=1, in_slope
     if e0 is not None:
         es = x.element_size()
         _lib.timer.stop("vits_conv1d_cl_wgrad", e0, (2.0 * b * t_out * c_out * c_in * k,
-                                                      es * (b * t * c_in + b * t_out * c_out) + 4.0 * k * c_out * c_in))
+                                                      es * (b * t * c_in + b * t_out * c_out) + 4.0 * k * c_out * c_in),
+                        shape=f"b{b} t{t} ci{c_in} co{c_out} k{k} d{dil} s{stride} {str(x.dtype)[6:]}")
     _lib.check(rc, "vits_conv1d_cl_wgrad")
     return out

@@ -38,49 +38,58 @@ def prep_conv(weight):
 
 
 class ConvCLFn(torch.autograd.Function):
-    """y = mask_out( conv(lrelu_slope(mask_in(x)), w) + bias ), x [b,t,c_in] channels-last (may be a channel
-    slice), w: arena handle or fp32 kernel-layout weight [k][c_out][c_in].  Data and weight gradients by
-    the same HIP kernels."""
+    """y = mask_out( conv(lrelu_slope(mask_in(x)), w) + bias + res ), x [b,t,c_in] channels-last (may be a
+    channel slice), w: arena handle or fp32 kernel-layout weight [k][c_out][c_in].  Data and weight gradients
+    by the same HIP kernels (in_slope = 0 is a fused ReLU on the input)."""
 
     @staticmethod
-    def forward(ctx, dtype, x, w, bias, lengths, dil, pad, in_slope, mask_in, mask_out):
+    def forward(ctx, dtype, x, w, bias, lengths, dil, pad, in_slope, mask_in, mask_out, res, stride):
         xd = x.detach()
         if xd.dtype != dtype:
             xd = xd.to(dtype)
         R = WA.resolve(w, dtype)
         flags = (K.CONV_MASK_IN if mask_in else 0) | (K.CONV_MASK_OUT if mask_out else 0)
-        y = K.conv1d_cl_raw(xd, R.fwd, None if bias is None else bias.detach().float(), lengths=lengths, dil=dil, pad=pad,
-                            in_slope=in_slope, flags=flags)
+        rd = None if res is None else res.detach().to(dtype).contiguous()
+        y = K.conv1d_cl_raw(xd, R.fwd, None if bias is None else bias.detach().float(), res=rd, lengths=lengths, dil=dil, pad=pad,
+                            stride=stride, in_slope=in_slope, flags=flags)
         ctx.save_for_backward(xd)
         ctx.R = R
-        ctx.lengths, ctx.cfg, ctx.has_bias, ctx.x_dtype = lengths, (dil, pad, in_slope, mask_in, mask_out), bias is not None, x.dtype
+        ctx.lengths, ctx.cfg, ctx.has_bias, ctx.x_dtype = lengths, (dil, pad, in_slope, mask_in, mask_out, stride), bias is not None, x.dtype
+        ctx.res_dtype = None if res is None else res.dtype
         return y
 
     @staticmethod
     def backward(ctx, dy):
         (xd,) = ctx.saved_tensors
         R = ctx.R
-        dil, pad, in_slope, mask_in, mask_out = ctx.cfg
+        dil, pad, in_slope, mask_in, mask_out, stride = ctx.cfg
         k = R.fwd.size(0)
         dy = dy.contiguous()
-        if mask_out:                                    # d(y * mask): zero rows first (one pass, reused three times)
+        if mask_out:                                    # d(y * mask): zero rows first (one pass, reused)
             t = dy.size(1)
             dy = dy * (torch.arange(t, device=dy.device)[None, :, None] < ctx.lengths[:, None, None])
-        dw = K.conv1d_cl_wgrad_raw(xd, dy, k, lengths=ctx.lengths, dil=dil, pad=pad, in_slope=in_slope,
-                                   flags=K.CONV_MASK_IN if mask_in else 0, out=R.dw)
-        db = dy.sum((0, 1), dtype=torch.float32) if ctx.has_bias else None
+        dw = db = None
+        if ctx.needs_input_grad[2]:
+            dw = K.conv1d_cl_wgrad_raw(xd, dy, k, lengths=ctx.lengths, dil=dil, pad=pad, stride=stride, in_slope=in_slope,
+                                       flags=K.CONV_MASK_IN if mask_in else 0, out=R.dw)
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            db = dy.sum((0, 1), dtype=torch.float32)
         dx = None
         if ctx.needs_input_grad[1]:
+            assert stride == 1, "data gradient of a strided convolution is not built yet"
             xs = xd if xd.is_contiguous() else xd.contiguous()
             dx = K.conv1d_cl_raw(dy, WA.bwd_operand(R), None, mg_src=xs if in_slope != 1.0 else None, lengths=ctx.lengths, dil=dil,
                                  pad=dil * (k - 1) - pad, mg_slope=in_slope, flags=K.CONV_MASK_OUT if mask_in else 0)
             if dx.dtype != ctx.x_dtype:
                 dx = dx.to(ctx.x_dtype)
-        return None, dx, dw, db, None, None, None, None, None, None
+        dres = None
+        if ctx.res_dtype is not None and ctx.needs_input_grad[10]:
+            dres = dy if dy.dtype == ctx.res_dtype else dy.to(ctx.res_dtype)
+        return None, dx, dw, db, None, None, None, None, None, None, dres, None
 
 
-def conv_cl(x, w, bias=None, lengths=None, dil=1, pad=0, in_slope=1.0, mask_in=False, mask_out=False, dtype=None):
-    return ConvCLFn.apply(dtype or compute_dtype(), x, w, bias, lengths, dil, pad, in_slope, mask_in, mask_out)
+def conv_cl(x, w, bias=None, lengths=None, dil=1, pad=0, in_slope=1.0, mask_in=False, mask_out=False, dtype=None, res=None, stride=1):
+    return ConvCLFn.apply(dtype or compute_dtype(), x, w, bias, lengths, dil, pad, in_slope, mask_in, mask_out, res, stride)
 
 
 def weight_of(module, part=None, pad_in=0, pad_out=0):

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Per-shape time of this repo's conv kernels inside one fine-tune step (eager, HIP events per launch)."""
+import os, sys
+os.environ["VITS_TIMER_DETAIL"] = "1"
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import torch
+from importlib import import_module
+P = import_module("personalized_text-to-speech_amd"); cfgs = import_module("personalized_text-to-speech_amd.configs"); tr = import_module("personalized_text-to-speech_amd.train")
+hps = cfgs.get("modified_finetune_speaker")
+ft = tr.FineTuner(hps, "cuda:0", amp=True)
+batch = tr.synthetic_batch(hps, 16, (200, 500), "cuda:0")
+for _ in range(3): ft.step(batch)
+P._lib.timer.enabled = True; P._lib.timer.reset()
+for _ in range(3): ft.step(batch)
+torch.cuda.synchronize()
+rows = []
+for name, sm in P._lib.timer.summary().items():
+    fl, by = sm["units_total"]
+    rows.append((sm["total_ms"] / 3, sm["calls"] / 3, sm["avg_ms"] * 1e3, fl / (sm["total_ms"] * 1e-3) / 1e12, by / (sm["total_ms"] * 1e-3) / 1e9, name))
+rows.sort(reverse=True)
+print(f"{'ms/step':>8} {'calls':>6} {'avg_us':>8} {'TFLOP/s':>8} {'GB/s':>8}  kernel shape")
+for r in rows[:45]:
+    print(f"{r[0]:8.3f} {r[1]:6.1f} {r[2]:8.1f} {r[3]:8.1f} {r[4]:8.1f}  {r[5]}")
