@@ -23,7 +23,7 @@ BACKENDS = {
     "stochastic duration predictor (DDSConv: dwconv, LayerNorm+GELU, 1x1; spline; fwd+bwd)": "hip",
     "weight preparation (weight-norm, layouts, dtype; fwd+bwd)": "hip",
     "text encoder (rel. attention, FFN, LayerNorm)": "rocm",
-    "stft / mel": "rocm",
+    "stft (framed windowed DFT as an exact-fp32 MFMA product; fwd+bwd)": "hip",
     "discriminators (MIOpen, as BASELINE.json allows)": "rocm",
     "AdamW (torch fused multi-tensor)": "rocm",
 }
@@ -114,14 +114,60 @@ def rq_spline(inputs, uw, uh, ud, inverse, tail_bound, min_bin_width=1e-3, min_b
 
 
 # ------------------------------------------------------------------ STFT
+_dft_cache = {}
+
+
+def _dft_operand(n_fft, hop, window):
+    """Windowed real-DFT basis as a tap-major convolution operand [n_fft/hop][2*Fp][hop] (fp32):
+    rows [0, F) = w[n] cos(2 pi c n / n_fft), rows [Fp, Fp+F) = -w[n] sin(...), F = n_fft/2+1, Fp = F rounded up to 8."""
+    key = (n_fft, hop, window.data_ptr(), str(window.device))
+    op = _dft_cache.get(key)
+    if op is None:
+        from . import weight_arena
+        F_, taps = n_fft // 2 + 1, n_fft // hop
+        Fp = (F_ + 7) // 8 * 8
+        n = torch.arange(n_fft, dtype=torch.float64, device=window.device)
+        c = torch.arange(F_, dtype=torch.float64, device=window.device)
+        ang = 2 * math.pi * c[:, None] * n[None, :] / n_fft
+        w64 = window.double()[None, :]
+        basis = torch.zeros(2 * Fp, n_fft, dtype=torch.float64, device=window.device)
+        basis[:F_] = torch.cos(ang) * w64
+        basis[Fp:Fp + F_] = -torch.sin(ang) * w64
+        op = basis.view(2 * Fp, taps, hop).permute(1, 0, 2).contiguous().float()        # [taps][2Fp][hop]
+        weight_arena.register_constant(op)
+        _dft_cache[key] = op
+    return op
+
+
 def stft_magnitude(y, n_fft, hop, win, window):
-    """reflect-pad (n_fft-hop)/2, framed real DFT with `window`, sqrt(re^2+im^2+1e-6)
-    (reference mel_processing.py:63-69).  y [b, t] -> [b, n_fft/2+1, frames]."""
+    """reflect-pad (n_fft-hop)/2, framed windowed real DFT, sqrt(re^2+im^2+1e-6)
+    (reference mel_processing.py:63-69).  y [b, t] -> [b, n_fft/2+1, frames].
+
+    On the GPU the framed DFT is an exact-fp32 matrix-core product: the padded signal is viewed as rows of
+    `hop` samples, a frame is n_fft/hop consecutive rows, so the STFT is vits_conv1d_cl with k = n_fft/hop taps
+    over a windowed cos/sin basis (fp32 MFMA = fmaf chain).  Falls back to torch.stft (rocFFT) when
+    hop does not divide n_fft or the window is not n_fft long."""
     pad = int((n_fft - hop) / 2)
     yp = F.pad(y.unsqueeze(1), (pad, pad), mode="reflect").squeeze(1)
-    spec = torch.stft(yp, n_fft, hop_length=hop, win_length=win, window=window, center=False,
-                      normalized=False, onesided=True, return_complex=True)
-    return torch.sqrt(spec.real.pow(2) + spec.imag.pow(2) + 1e-6)
+    if not (y.is_cuda and n_fft % hop == 0 and win == n_fft and hop % 4 == 0):
+        spec = torch.stft(yp, n_fft, hop_length=hop, win_length=win, window=window, center=False,
+                          normalized=False, onesided=True, return_complex=True)
+        return torch.sqrt(spec.real.pow(2) + spec.imag.pow(2) + 1e-6)
+    from . import wn_cl
+    b, tp = yp.shape
+    taps = n_fft // hop
+    frames = (tp - n_fft) // hop + 1
+    rows = frames + taps - 1
+    need = rows * hop
+    yp = yp.float()
+    if tp < need:
+        yp = F.pad(yp, (0, need - tp))
+    x = yp[:, :need].reshape(b, rows, hop)
+    op = _dft_operand(n_fft, hop, window.float())
+    ri = wn_cl.conv_cl(x, op, dtype=torch.float32)                     # [b, frames, 2*Fp]
+    F_, Fp = n_fft // 2 + 1, op.size(1) // 2
+    mag = torch.sqrt(ri[..., :F_].pow(2) + ri[..., Fp:Fp + F_].pow(2) + 1e-6)
+    return mag.transpose(1, 2)
 
 
 # ================================================================================================

@@ -415,7 +415,20 @@ class SynthesizerTrn(nn.Module):
                     out.append(Spec(rs, "skip"))
             return out
 
+        def dds_specs(dds):
+            return [Spec(c) for c in dds.convs_1x1]
+
         specs = [Spec(net.enc_q.pre, c_in_p=(net.enc_q.in_channels + 7) // 8 * 8)] + wn_specs(net.enc_q.enc) + [Spec(net.enc_q.proj)]
+        # text encoder: q/k/v/o projections, FFN convolutions, output projection
+        for att, ffn in zip(net.enc_p.encoder.attn_layers, net.enc_p.encoder.ffn_layers):
+            specs += [Spec(att.conv_q), Spec(att.conv_k), Spec(att.conv_v), Spec(att.conv_o), Spec(ffn.conv_1), Spec(ffn.conv_2)]
+        # stochastic duration predictor: every 192-channel 1x1 convolution; the 29-column spline projections padded to 32
+        if isinstance(net.dp, StochasticDurationPredictor):
+            dp = net.dp
+            specs += [Spec(dp.pre), Spec(dp.proj), Spec(dp.post_proj)] + dds_specs(dp.convs) + dds_specs(dp.post_convs)
+            for fl in list(dp.flows) + list(dp.post_flows):
+                if isinstance(fl, modules.ConvFlow):
+                    specs += dds_specs(fl.convs) + [Spec(fl.proj, c_out_p=(fl.proj.out_channels + 7) // 8 * 8)]
         for fl in net.flow.flows:
             if isinstance(fl, modules.ResidualCouplingLayer):
                 specs += [Spec(fl.pre)] + wn_specs(fl.enc) + [Spec(fl.post)]

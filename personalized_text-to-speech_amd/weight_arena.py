@@ -130,8 +130,21 @@ class Resolved:
         self.fwd, self.bwd, self.dw = fwd, bwd, dw
 
 
+_constants = {}            # data_ptr -> Resolved, for constant operands registered with register_constant()
+
+
+def register_constant(w_fwd):
+    """A constant (non-trainable) kernel-layout operand, e.g. a DFT basis: its data-gradient copy is made once."""
+    r = Resolved(w_fwd, w_fwd.flip(0).transpose(1, 2).contiguous(), None)
+    _constants[w_fwd.data_ptr()] = r
+    return w_fwd
+
+
 def resolve(w, dtype):
-    """w: a handle from an arena, or any fp32 kernel-layout weight [k][c_out][c_in] (fallback)."""
+    """w: a handle from an arena, a registered constant, or any fp32 kernel-layout weight [k][c_out][c_in] (fallback)."""
+    c = _constants.get(w.data_ptr())
+    if c is not None and c.fwd.dtype == dtype and c.fwd.shape == w.shape:
+        return c
     hit = _registry.get(w.data_ptr())
     if hit is not None and hit[0].dtype == dtype and tuple(w.shape) == tuple(hit[0].handles[hit[1]].shape):
         a, i = hit

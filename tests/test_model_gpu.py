@@ -96,3 +96,21 @@ def test_train_step_runs_and_learns(pkg):
     assert b["loss_disc"] < a["loss_disc"]
     missing = [n for n, p in ft.net_g.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all()]
     assert not missing, missing[:5]
+
+
+def test_mel_of_generated_audio_matches_oracle(pkg):
+    """mel_spectrogram_torch through the exact-fp32 MFMA DFT vs the oracle's torch.stft path, values and
+    the gradient wrt the waveform (it sits on the generator's critical path, finetune_speaker_v2.py:192-201)."""
+    from oracle import vits_torch as O
+    torch.manual_seed(0)
+    y = (torch.rand(3, 8192, device="cuda:0") * 1.6 - 0.8)
+    ya, yb = y.clone().requires_grad_(True), y.clone().requires_grad_(True)
+    got = pkg.mel_processing.mel_spectrogram_torch(ya, 1024, 80, 22050, 256, 1024, 0.0, None)
+    basis = O.mel_basis_slaney(22050, 1024, 80, 0.0, None).cuda()
+    want = O.spec_to_mel(O.spectrogram(yb, 1024, 256, 1024), basis)
+    assert got.shape == want.shape == (3, 80, 32)
+    assert rel_err(got, want) < 1e-4
+    probe = torch.randn_like(want)
+    (got * probe).sum().backward()
+    (want * probe).sum().backward()
+    assert rel_err(ya.grad, yb.grad) < 1e-3
