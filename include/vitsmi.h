@@ -106,6 +106,8 @@ int vits_mas_f32(const float* neg_cent, void* path, int path_dtype,
                                    y[.., c] = v * sigmoid(b) * (1 - tanh(a)^2),  y[.., c + gate_h] = v * tanh(a) * sigmoid(b) * (1 - sigmoid(b));
                                    y and mg_src have 2*gate_h columns */
 
+#define VITS_CONV_OUT_LRELU 128 /* y = leaky_relu(., out_slope) applied after residual/scale (discriminator feature maps) */
+
 /* All sizes in elements.  Zero in ldx / ldy / ldy2 / stride means "dense" / 1. */
 typedef struct vits_conv_desc {
   int32_t dtype;            /* VITS_DT_BF16 | VITS_DT_F32 (x, w, y, y2, res, mg_src share it)           */
@@ -116,7 +118,7 @@ typedef struct vits_conv_desc {
   int32_t ldy;              /* row pitch of y, res and mg_src                                             */
   int32_t ldy2;             /* row pitch of y2                                                            */
   int32_t gate_h;           /* H of the gate flags                                                        */
-  float in_slope, mg_slope, out_scale, reserved;
+  float in_slope, mg_slope, out_scale, out_slope;
   const void* x;  const void* w;  const float* bias;  const float* bias_b;
   const void* res;  const void* mg_src;  void* y;  void* y2;  const int32_t* lengths;
 } vits_conv_desc;

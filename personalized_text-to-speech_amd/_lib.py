@@ -43,7 +43,7 @@ class ConvDesc(ctypes.Structure):
     """vits_conv_desc of include/vitsmi.h"""
     _fields_ = [(n, ctypes.c_int32) for n in ("dtype", "b", "t", "c_in", "c_out", "k", "dil", "pad", "stride", "flags",
                                               "ldx", "ldy", "ldy2", "gate_h")] + \
-               [(n, c_float) for n in ("in_slope", "mg_slope", "out_scale", "reserved")] + \
+               [(n, c_float) for n in ("in_slope", "mg_slope", "out_scale", "out_slope")] + \
                [(n, c_void_p) for n in ("x", "w", "bias", "bias_b", "res", "mg_src", "y", "y2", "lengths")]
 
 

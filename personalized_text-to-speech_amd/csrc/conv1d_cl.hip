@@ -289,6 +289,7 @@ __global__ __launch_bounds__(kThreads) void conv1d_cl_kernel(ConvArgs args) {
       }
       if (MG) v *= (to_f(MG[o]) > 0.f) ? 1.0f : a.mg_slope;
       if (R && res_after) v += to_f(R[o]);
+      if (a.flags & VITS_CONV_OUT_LRELU) v = v > 0.f ? v : v * a.out_slope;
       if (a.flags & VITS_CONV_TANH) v = tanhf(v);
       if ((a.flags & VITS_CONV_MASK_OUT) && t >= len) v = 0.f;
       if (a.flags & VITS_CONV_ACCUM) v += to_f(Y[o]);

@@ -24,7 +24,7 @@ BACKENDS = {
     "weight preparation (weight-norm, layouts, dtype; fwd+bwd)": "hip",
     "text encoder (rel. attention, FFN, LayerNorm)": "rocm",
     "stft (framed windowed DFT as an exact-fp32 MFMA product; fwd+bwd)": "hip",
-    "discriminators (MIOpen, as BASELINE.json allows)": "rocm",
+    "discriminators (MIOpen, as BASELINE.json allows; HIP path for the period discriminators exists, off by default)": "rocm",
     "AdamW (torch fused multi-tensor)": "rocm",
 }
 
@@ -174,7 +174,7 @@ def stft_magnitude(y, n_fft, hop, win, window):
 # Channels-last HIP convolution (csrc/conv1d_cl.hip).  Raw launcher: tensors are [b, t, c]
 # contiguous, weights are tap-major [k, c_out, c_in] in the activation dtype.
 # ================================================================================================
-CONV_MASK_IN, CONV_MASK_OUT, CONV_TANH, CONV_ACCUM, CONV_RES_AFTER, CONV_GATE, CONV_GATE_BWD = 1, 2, 4, 8, 16, 32, 64
+CONV_MASK_IN, CONV_MASK_OUT, CONV_TANH, CONV_ACCUM, CONV_RES_AFTER, CONV_GATE, CONV_GATE_BWD, CONV_OUT_LRELU = 1, 2, 4, 8, 16, 32, 64, 128
 _DT = {torch.float32: 0, torch.bfloat16: 2}
 
 
@@ -187,7 +187,7 @@ def _rows(t, name):
 
 
 def conv1d_cl_raw(x, w, bias=None, bias_b=None, res=None, mg_src=None, out=None, lengths=None, dil=1, pad=0, stride=1,
-                  in_slope=1.0, mg_slope=1.0, out_scale=1.0, flags=0, gate_h=0, out2=None):
+                  in_slope=1.0, mg_slope=1.0, out_scale=1.0, flags=0, gate_h=0, out2=None, out_slope=None):
     """Launch vits_conv1d_cl.  x [b,t,c_in], w [k,c_out,c_in] (tap-major) in the same dtype; see
     include/vitsmi.h for the fused prologue/epilogue.  Returns y (allocated unless `out` is given)."""
     _lib.require_cuda(x, w)
@@ -208,9 +208,11 @@ def conv1d_cl_raw(x, w, bias=None, bias_b=None, res=None, mg_src=None, out=None,
         assert tns is None or (tns.dtype == torch.float32 and tns.is_contiguous())
     assert lengths is None or lengths.dtype == torch.int32
     p = lambda v: None if v is None else v.data_ptr()
+    if out_slope is not None:
+        flags |= CONV_OUT_LRELU
     d = _lib.ConvDesc(dtype=_DT[x.dtype], b=b, t=t, c_in=c_in, c_out=c_out, k=k, dil=dil, pad=pad, stride=stride, flags=int(flags),
                       ldx=_rows(x, "x"), ldy=ldy, ldy2=0 if out2 is None else _rows(out2, "out2"), gate_h=gate_h,
-                      in_slope=float(in_slope), mg_slope=float(mg_slope), out_scale=float(out_scale), reserved=0.0,
+                      in_slope=float(in_slope), mg_slope=float(mg_slope), out_scale=float(out_scale), out_slope=float(out_slope or 0.0),
                       x=x.data_ptr(), w=w.data_ptr(), bias=p(bias), bias_b=p(bias_b), res=p(res), mg_src=p(mg_src),
                       y=out.data_ptr(), y2=p(out2), lengths=p(lengths))
     import ctypes

@@ -273,10 +273,16 @@ class _WNConv2dK1(nn.Module):
         super().__init__()
         proto = nn.Conv2d(cin, cout, (k, 1), (s, 1), padding=(p, 0))
         self.stride, self.padding = (s, 1), (p, 0)
+        self.in_channels, self.out_channels, self.kernel_size = cin, cout, k
         self.bias = nn.Parameter(proto.bias.data)
         v = proto.weight.data
         self.weight_g = nn.Parameter(torch.linalg.vector_norm(v, 2, dim=(1, 2, 3), keepdim=True))
         self.weight_v = nn.Parameter(v)
+
+    @property
+    def weight(self):
+        """weight-normed weight as a Conv1d weight [c_out, c_in, k]"""
+        return K.weight_norm(self.weight_v, self.weight_g).squeeze(-1)
 
     def forward(self, x):
         w = K.weight_norm(self.weight_v, self.weight_g)
@@ -298,7 +304,16 @@ class DiscriminatorP(nn.Module):
             _WNConv2dK1(1024, 1024, kernel_size, 1, p)])
         self.conv_post = _WNConv2dK1(1024, 1, 3, 1, 1)
 
+    # The HIP path is correct (tests/test_disc_logic_cpu.py, test_model_gpu.py) but today slower than MIOpen's
+    # implicit-GEMM kernels on these shapes (deep layers have 10-51 rows per folded batch element, so the
+    # per-element time tiling of vits_conv1d_cl wastes most of each tile, and the strided data gradient uses
+    # zero insertion): 90 vs 80 ms/step.  It is switched on once the flat (b,t)-row tiling lands.
+    use_hip = False
+
     def forward(self, x):
+        return self.forward_hip(x) if DiscriminatorP.use_hip else self.forward_rocm(x)
+
+    def forward_rocm(self, x):
         fmap = []
         b, c, t = x.shape
         if t % self.period != 0:                                   # pad first (models.py:319-322)
@@ -312,6 +327,32 @@ class DiscriminatorP(nn.Module):
         x = self.conv_post(x)
         fmap.append(x)
         return torch.flatten(x, 1, -1), fmap
+
+    def forward_hip(self, x):
+        """x [n, 1, t] -> (logits [n, t'], fmap list in the reference's [n, c, t', period] layout).
+        The (k, 1) convolutions act along t' only, so the period axis is folded into the batch and the five
+        layers run as strided channels-last 1-D convolutions on the MFMA kernel, leaky-relu fused as epilogue."""
+        from . import wn_cl
+        dtype = wn_cl.compute_dtype()
+        fmap = []
+        n, c, t = x.shape
+        p_ = self.period
+        if t % p_ != 0:                                             # pad first (models.py:319-322)
+            n_pad = p_ - (t % p_)
+            x = F.pad(x, (0, n_pad), "reflect")
+            t = t + n_pad
+        rows = t // p_
+        h = x.view(n, rows, p_).transpose(1, 2).reshape(n * p_, rows, 1)                  # [(n, w), t', 1]
+        h = F.pad(h, (0, 7)).to(dtype)                                                    # c_in 1 -> 8 (vector width), zero weights there
+        for i, l in enumerate(self.convs):
+            w = wn_cl.weight_of(l, pad_in=7 if i == 0 else 0)
+            h = wn_cl.conv_cl(h, w, l.bias, pad=l.padding[0], stride=l.stride[0], out_slope=modules.LRELU_SLOPE, dtype=dtype)
+            fmap.append(h.view(n, p_, h.size(1), h.size(2)).permute(0, 3, 2, 1))          # [n, c, t', period] view
+        l = self.conv_post
+        y = wn_cl.conv_cl(h, wn_cl.weight_of(l, pad_out=7), wn_cl.bias_of(l, 7), pad=l.padding[0], dtype=dtype)[..., :1]
+        y = y.reshape(n, p_, y.size(1), 1).permute(0, 3, 2, 1)                            # [n, 1, t'', period]
+        fmap.append(y)
+        return torch.flatten(y, 1, -1), fmap
 
 
 class DiscriminatorS(nn.Module):
@@ -349,14 +390,30 @@ class MultiPeriodDiscriminator(nn.Module):
         """Real and generated waveforms go through each discriminator as ONE batch of 2b (the
         reference runs them as two passes, models.py:375-377; the convolutions have no cross-batch
         coupling, so the results are identical and every kernel sees twice the rows)."""
+        from . import weight_arena
         b = y.size(0)
         yy = torch.cat([y, y_hat], 0)
         y_d_rs, y_d_gs, fmap_rs, fmap_gs = [], [], [], []
-        for d in self.discriminators:
-            out, fmap = d(yy)
+        if DiscriminatorP.use_hip:
+            with weight_arena.scope(self, MultiPeriodDiscriminator._arena_specs):
+                outs = [d(yy) for d in self.discriminators]
+        else:
+            outs = [d(yy) for d in self.discriminators]
+        for out, fmap in outs:
             y_d_rs.append(out[:b]); y_d_gs.append(out[b:])
             fmap_rs.append([f[:b] for f in fmap]); fmap_gs.append([f[b:] for f in fmap])
         return y_d_rs, y_d_gs, fmap_rs, fmap_gs
+
+    @staticmethod
+    def _arena_specs(net):
+        from .weight_arena import Spec
+        specs = []
+        for d in net.discriminators:
+            if isinstance(d, DiscriminatorP):
+                specs.append(Spec(d.convs[0], c_in_p=8))
+                specs += [Spec(l) for l in d.convs[1:]]
+                specs.append(Spec(d.conv_post, c_out_p=8))
+        return specs
 
 
 class SynthesizerTrn(nn.Module):

@@ -30,7 +30,7 @@ class Spec:
         has_g = hasattr(module, "weight_g")
         self.v = module.weight_v if has_g else module.weight
         self.g = module.weight_g if has_g else None
-        d0, d1, k = self.v.shape
+        d0, d1, k = self.v.shape[:3]              # Conv2d (k, 1) weights [c_out, c_in, k, 1] are read as [c_out, c_in, k]
         self.k = k
         if transpose:                         # ConvTranspose1d [c_in][c_out][k], rows = input channels
             self.c_in, self.c_out = d0, d1

@@ -43,7 +43,7 @@ class ConvCLFn(torch.autograd.Function):
     by the same HIP kernels (in_slope = 0 is a fused ReLU on the input)."""
 
     @staticmethod
-    def forward(ctx, dtype, x, w, bias, lengths, dil, pad, in_slope, mask_in, mask_out, res, stride):
+    def forward(ctx, dtype, x, w, bias, lengths, dil, pad, in_slope, mask_in, mask_out, res, stride, out_slope):
         xd = x.detach()
         if xd.dtype != dtype:
             xd = xd.to(dtype)
@@ -51,20 +51,22 @@ class ConvCLFn(torch.autograd.Function):
         flags = (K.CONV_MASK_IN if mask_in else 0) | (K.CONV_MASK_OUT if mask_out else 0)
         rd = None if res is None else res.detach().to(dtype).contiguous()
         y = K.conv1d_cl_raw(xd, R.fwd, None if bias is None else bias.detach().float(), res=rd, lengths=lengths, dil=dil, pad=pad,
-                            stride=stride, in_slope=in_slope, flags=flags)
-        ctx.save_for_backward(xd)
-        ctx.R = R
+                            stride=stride, in_slope=in_slope, flags=flags, out_slope=out_slope)
+        ctx.save_for_backward(xd, y if out_slope is not None else xd)
+        ctx.R, ctx.out_slope = R, out_slope
         ctx.lengths, ctx.cfg, ctx.has_bias, ctx.x_dtype = lengths, (dil, pad, in_slope, mask_in, mask_out, stride), bias is not None, x.dtype
         ctx.res_dtype = None if res is None else res.dtype
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        (xd,) = ctx.saved_tensors
+        xd, ysave = ctx.saved_tensors
         R = ctx.R
         dil, pad, in_slope, mask_in, mask_out, stride = ctx.cfg
         k = R.fwd.size(0)
         dy = dy.contiguous()
+        if ctx.out_slope is not None:                   # chain rule of the fused output leaky-relu (sign of y = sign of pre-activation)
+            dy = dy * torch.where(ysave > 0, 1.0, ctx.out_slope).to(dy.dtype)
         if mask_out:                                    # d(y * mask): zero rows first (one pass, reused)
             t = dy.size(1)
             dy = dy * (torch.arange(t, device=dy.device)[None, :, None] < ctx.lengths[:, None, None])
@@ -76,20 +78,24 @@ class ConvCLFn(torch.autograd.Function):
             db = dy.sum((0, 1), dtype=torch.float32)
         dx = None
         if ctx.needs_input_grad[1]:
-            assert stride == 1, "data gradient of a strided convolution is not built yet"
             xs = xd if xd.is_contiguous() else xd.contiguous()
-            dx = K.conv1d_cl_raw(dy, WA.bwd_operand(R), None, mg_src=xs if in_slope != 1.0 else None, lengths=ctx.lengths, dil=dil,
+            dyu = dy
+            if stride != 1:                             # zero-insertion: dY on the input's time grid, then the stride-1 data gradient
+                dyu = dy.new_zeros(xd.size(0), xd.size(1), dy.size(2))
+                dyu[:, 0:(dy.size(1) - 1) * stride + 1:stride] = dy
+            dx = K.conv1d_cl_raw(dyu, WA.bwd_operand(R), None, mg_src=xs if in_slope != 1.0 else None, lengths=ctx.lengths, dil=dil,
                                  pad=dil * (k - 1) - pad, mg_slope=in_slope, flags=K.CONV_MASK_OUT if mask_in else 0)
             if dx.dtype != ctx.x_dtype:
                 dx = dx.to(ctx.x_dtype)
         dres = None
         if ctx.res_dtype is not None and ctx.needs_input_grad[10]:
             dres = dy if dy.dtype == ctx.res_dtype else dy.to(ctx.res_dtype)
-        return None, dx, dw, db, None, None, None, None, None, None, dres, None
+        return None, dx, dw, db, None, None, None, None, None, None, dres, None, None
 
 
-def conv_cl(x, w, bias=None, lengths=None, dil=1, pad=0, in_slope=1.0, mask_in=False, mask_out=False, dtype=None, res=None, stride=1):
-    return ConvCLFn.apply(dtype or compute_dtype(), x, w, bias, lengths, dil, pad, in_slope, mask_in, mask_out, res, stride)
+def conv_cl(x, w, bias=None, lengths=None, dil=1, pad=0, in_slope=1.0, mask_in=False, mask_out=False, dtype=None, res=None, stride=1,
+            out_slope=None):
+    return ConvCLFn.apply(dtype or compute_dtype(), x, w, bias, lengths, dil, pad, in_slope, mask_in, mask_out, res, stride, out_slope)
 
 
 def weight_of(module, part=None, pad_in=0, pad_out=0):

@@ -6,7 +6,7 @@ import torch.nn.functional as F
 
 
 def conv1d_cl_raw(x, w, bias=None, bias_b=None, res=None, mg_src=None, out=None, lengths=None, dil=1, pad=0, stride=1,
-                  in_slope=1.0, mg_slope=1.0, out_scale=1.0, flags=0, gate_h=0, out2=None):
+                  in_slope=1.0, mg_slope=1.0, out_scale=1.0, flags=0, gate_h=0, out2=None, out_slope=None):
     b, t, c_in = x.shape
     k, c_out, c_in_w = w.shape
     assert c_in_w == c_in, (tuple(x.shape), tuple(w.shape))
@@ -47,6 +47,8 @@ def conv1d_cl_raw(x, w, bias=None, bias_b=None, res=None, mg_src=None, out=None,
                 v = v * torch.where(mg_src.float() > 0, 1.0, mg_slope)
             if res is not None and after:
                 v = v + res.float()
+            if out_slope is not None:
+                v = F.leaky_relu(v, out_slope)
             if flags & 4:
                 v = torch.tanh(v)
             if flags & 2:

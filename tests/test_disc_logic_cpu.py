@@ -1,0 +1,37 @@
+"""CPU: the period discriminators on the channels-last kernels (kernels emulated): logits, feature maps
+(reference layout) and gradients wrt the input waveform and the parameters equal the oracle."""
+import pytest
+import torch
+
+import cl_emul
+from model_util import rel_err
+from oracle import vits_torch as O
+
+
+@pytest.fixture()
+def emulated(pkg, monkeypatch):
+    monkeypatch.setattr(pkg.kernels, "conv1d_cl_raw", cl_emul.conv1d_cl_raw)
+    monkeypatch.setattr(pkg.kernels, "conv1d_cl_wgrad_raw", cl_emul.conv1d_cl_wgrad_raw)
+    cl_emul.install_arena_emulation(monkeypatch)
+    return pkg
+
+
+@pytest.mark.parametrize("period", [2, 3, 5])
+def test_discriminator_p(emulated, period):
+    pkg = emulated
+    torch.manual_seed(period)
+    d = pkg.models.DiscriminatorP(period)
+    sd = {"d." + k: v.detach().clone().requires_grad_(True) for k, v in d.state_dict().items()}
+    x = (torch.rand(2, 1, 500) * 2 - 1)
+    xo, xp = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    lo, fo = O.disc_p(sd, "d", xo, period)
+    lp, fp = d.forward_hip(xp)
+    assert lp.shape == lo.shape and rel_err(lp, lo) < 1e-5
+    for a, b in zip(fp, fo):
+        assert a.shape == b.shape and rel_err(a, b) < 1e-5
+    probe = [torch.randn_like(f) for f in fo]
+    sum((f * q).sum() for f, q in zip(fo, probe)).backward()
+    sum((f.float() * q).sum() for f, q in zip(fp, probe)).backward()
+    assert rel_err(xp.grad, xo.grad) < 2e-5
+    for k, p in d.named_parameters():
+        assert rel_err(p.grad, sd["d." + k].grad) < 5e-5, k

@@ -114,3 +114,22 @@ def test_mel_of_generated_audio_matches_oracle(pkg):
     (got * probe).sum().backward()
     (want * probe).sum().backward()
     assert rel_err(ya.grad, yb.grad) < 1e-3
+
+
+def test_period_discriminator_hip_path_matches_rocm_path(pkg):
+    """The channels-last HIP implementation of DiscriminatorP (off by default) against the MIOpen path."""
+    torch.manual_seed(4)
+    d = pkg.models.DiscriminatorP(3).cuda()
+    x = (torch.rand(4, 1, 8192, device="cuda:0") * 2 - 1)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    la, fa = d.forward_hip(xa)
+    lb, fb = d.forward_rocm(xb)
+    assert rel_err(la, lb) < 1e-3
+    for a, b in zip(fa, fb):
+        assert a.shape == b.shape and rel_err(a, b) < 1e-3
+    la.pow(2).sum().backward(); ga = {k: p.grad.clone() for k, p in d.named_parameters()}
+    d.zero_grad()
+    lb.pow(2).sum().backward()
+    assert rel_err(xa.grad, xb.grad) < 2e-3
+    for k, p in d.named_parameters():
+        assert rel_err(ga[k], p.grad) < 2e-3, k
