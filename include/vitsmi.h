@@ -140,6 +140,7 @@ typedef struct vits_wgrad_desc {
   float in_slope, reserved;
   const void* x;  const void* dy;  float* dw;  void* workspace;  size_t workspace_bytes;
   const int32_t* lengths;
+  float* dbias;             /* optional float32[c_out]: (+)= sum_{b,t} dy[b][t][co] (rows masked like dy), same launch */
 } vits_wgrad_desc;
 
 size_t vits_conv1d_cl_wgrad_workspace(int b, int t_out, int c_in, int c_out, int k);

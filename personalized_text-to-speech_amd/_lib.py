@@ -10,7 +10,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvitsmi.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_int = ctypes.c_int
 c_void_p = ctypes.c_void_p
@@ -59,7 +59,7 @@ class WgradDesc(ctypes.Structure):
                                               "ldx", "lddy")] + \
                [(n, c_float) for n in ("in_slope", "reserved")] + \
                [("x", c_void_p), ("dy", c_void_p), ("dw", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_size_t),
-                ("lengths", c_void_p)]
+                ("lengths", c_void_p), ("dbias", c_void_p)]
 
 
 _lib = None

@@ -34,6 +34,7 @@ struct WgradArgs {
   float in_slope;
   int flags;
   int ldx, lddy, stride;
+  float* partial_db;      // [S][Cout] per-split bias-gradient sums, or null
 };
 
 __device__ __forceinline__ float to_f(float v) { return v; }
@@ -153,6 +154,10 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
     }
   };
 
+  // bias gradient = column sums of dY: done by the workgroups of ci-tile 0 / tap-group 0 on their staged tiles
+  const bool do_db = (a.partial_db != nullptr) && (blockIdx.z == 0);
+  float db_acc = 0.f;
+
   const int n_chunks = a.B * a.chunks_per_item;
   int ch = blockIdx.x;
   if (ch < n_chunks) { load_chunk(ch); store_chunk(ch); }
@@ -160,6 +165,13 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
   for (; ch < n_chunks; ch += a.S) {
     const int nxt = ch + a.S;
     if (nxt < n_chunks) load_chunk(nxt);                  // in flight during this chunk's MFMAs
+    if (do_db) {
+      const int col = tid & 63, q4 = tid >> 6;
+      const T* dcol = reinterpret_cast<const T*>(ldsD) + col;
+#pragma unroll 8
+      for (int rr = q4 * (TK / 4); rr < (q4 + 1) * (TK / 4); ++rr)
+        db_acc += to_f(*reinterpret_cast<const T*>(reinterpret_cast<const unsigned char*>(dcol) + (size_t)rr * PITCH));
+    }
 
     if constexpr (sizeof(T) == 2) {
       // transposing reads: within a 16-lane group, lane 4q+p addresses row q, columns 4p..4p+3 and
@@ -215,6 +227,15 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
     }
   }
 
+  if (do_db) {                                            // 4 row-quarters -> one sum per column, fixed order
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+    red[tid] = db_acc;
+    __syncthreads();
+    if (tid < 64 && co0 + tid < a.Cout)
+      a.partial_db[(size_t)blockIdx.x * a.Cout + co0 + tid] = red[tid] + red[tid + 64] + red[tid + 128] + red[tid + 192];
+    __syncthreads();
+  }
   // slab of this split: partial[split][tap][co][ci]
   float* P = a.partial + (size_t)blockIdx.x * a.K * a.Cout * a.Cin;
   const int ci = ci0 + wj * 32 + r;
@@ -290,7 +311,7 @@ int dispatch_k(const WgradArgs& a, hipStream_t s) {
 }  // namespace
 
 extern "C" size_t vits_conv1d_cl_wgrad_workspace(int b, int t_out, int c_in, int c_out, int k) {
-  return (size_t)pick_splits(b, t_out, c_in, c_out, k) * k * c_out * c_in * sizeof(float);
+  return (size_t)pick_splits(b, t_out, c_in, c_out, k) * ((size_t)k * c_out * c_in + c_out) * sizeof(float);
 }
 
 extern "C" int vits_conv1d_cl_wgrad(const vits_wgrad_desc* desc, void* stream) {
@@ -307,9 +328,11 @@ extern "C" int vits_conv1d_cl_wgrad(const vits_wgrad_desc* desc, void* stream) {
   if (d.workspace_bytes < vits_conv1d_cl_wgrad_workspace(d.b, t_out, d.c_in, d.c_out, d.k)) return VITS_E_BADARG;
   if (d.ldx <= 0) d.ldx = d.c_in;
   if (d.lddy <= 0) d.lddy = d.c_out;
-  WgradArgs a{d.x, d.dy, static_cast<float*>(d.workspace), d.lengths, d.b, d.t, t_out, d.c_in, d.c_out, d.k, d.dil, d.pad,
-              pick_splits(d.b, t_out, d.c_in, d.c_out, d.k), vits::ceil_div(t_out, TK), d.in_slope, d.flags,
-              d.ldx, d.lddy, d.stride};
+  const int S = pick_splits(d.b, t_out, d.c_in, d.c_out, d.k);
+  float* ws = static_cast<float*>(d.workspace);
+  WgradArgs a{d.x, d.dy, ws, d.lengths, d.b, d.t, t_out, d.c_in, d.c_out, d.k, d.dil, d.pad,
+              S, vits::ceil_div(t_out, TK), d.in_slope, d.flags, d.ldx, d.lddy, d.stride,
+              d.dbias ? ws + (size_t)S * d.k * d.c_out * d.c_in : nullptr};
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc;
   if (d.dtype == VITS_DT_BF16) {
@@ -325,5 +348,10 @@ extern "C" int vits_conv1d_cl_wgrad(const vits_wgrad_desc* desc, void* stream) {
   const size_t n = (size_t)d.k * d.c_out * d.c_in;          // multiple of 16 (c_in % 4 == 0 and c_out % 4 == 0)
   hipLaunchKernelGGL(reduce_slabs, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, a.partial, d.dw, n / 4, n, a.S,
                      (d.flags & VITS_CONV_ACCUM) ? 1 : 0);
+  if (d.dbias) {                                           // c_out % 4 == 0
+    const size_t nb = (size_t)d.c_out;
+    hipLaunchKernelGGL(reduce_slabs, dim3((unsigned)((nb / 4 + 255) / 256)), dim3(256), 0, s, a.partial_db, d.dbias, nb / 4, nb, a.S,
+                       (d.flags & VITS_CONV_ACCUM) ? 1 : 0);
+  }
   return vits::check_launch("vits_conv1d_cl_wgrad/reduce");
 }

@@ -40,75 +40,143 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return s;
 }
 
+// One WAVE per row (lane l owns channels l, l+64, ...: up to 16 per lane), 4 rows per workgroup step: the
+// row statistics are wave shuffles, no workgroup barrier inside the row loop.
+constexpr int NCMAX = 16;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
 template <typename T>
-__global__ void ln_act_fwd(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+__global__ __launch_bounds__(256) void ln_act_fwd(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                            const T* __restrict__ res, T* __restrict__ y, int rows, int C, float eps, int act, int rows_per_wg) {
-  __shared__ float red[16];
-  const int c = threadIdx.x;
-  const bool on = c < C;
-  const float g = on ? gamma[c] : 0.f, bt = on ? beta[c] : 0.f;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nc = (C + 63) >> 6;
+  float g[NCMAX], bt[NCMAX];
+#pragma unroll
+  for (int i = 0; i < NCMAX; ++i) {
+    const int c = lane + 64 * i;
+    g[i] = (i < nc && c < C) ? gamma[c] : 0.f;
+    bt[i] = (i < nc && c < C) ? beta[c] : 0.f;
+  }
   const int r0 = blockIdx.x * rows_per_wg;
-  for (int r = r0; r < r0 + rows_per_wg && r < rows; ++r) {
-    const float v = on ? to_f(x[(size_t)r * C + c]) : 0.f;
-    const float mean = block_sum(v, red) / C;
-    const float d = on ? v - mean : 0.f;
-    const float var = block_sum(d * d, red) / C;
-    float u = d * rsqrtf(var + eps) * g + bt;
-    if (act == 1) u = gelu_f(u);
-    if (on) {
-      if (res) u += to_f(res[(size_t)r * C + c]);
-      y[(size_t)r * C + c] = from_f<T>(u);
+  for (int r = r0 + wave; r < r0 + rows_per_wg && r < rows; r += 4) {
+    float v[NCMAX], sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCMAX; ++i) {
+      const int c = lane + 64 * i;
+      v[i] = (i < nc && c < C) ? to_f(x[(size_t)r * C + c]) : 0.f;
+      sum += v[i];
+    }
+    const float mean = wave_sum(sum) / C;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCMAX; ++i) {
+      const int c = lane + 64 * i;
+      v[i] = (i < nc && c < C) ? v[i] - mean : 0.f;
+      sq += v[i] * v[i];
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / C + eps);
+#pragma unroll
+    for (int i = 0; i < NCMAX; ++i) {
+      const int c = lane + 64 * i;
+      if (i < nc && c < C) {
+        float u = v[i] * rstd * g[i] + bt[i];
+        if (act == 1) u = gelu_f(u);
+        if (res) u += to_f(res[(size_t)r * C + c]);
+        y[(size_t)r * C + c] = from_f<T>(u);
+      }
     }
   }
 }
 
 template <typename T>
-__global__ void ln_act_bwd(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+__global__ __launch_bounds__(256) void ln_act_bwd(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                            const T* __restrict__ dy, T* __restrict__ dx, float* __restrict__ part, int rows, int C, float eps,
                            int act, int rows_per_wg) {
-  __shared__ float red[16];
-  const int c = threadIdx.x;
-  const bool on = c < C;
-  const float g = on ? gamma[c] : 0.f, bt = on ? beta[c] : 0.f;
-  float dg = 0.f, db = 0.f;
-  const int r0 = blockIdx.x * rows_per_wg;
-  for (int r = r0; r < r0 + rows_per_wg && r < rows; ++r) {
-    const float v = on ? to_f(x[(size_t)r * C + c]) : 0.f;
-    const float mean = block_sum(v, red) / C;
-    const float d = on ? v - mean : 0.f;
-    const float var = block_sum(d * d, red) / C;
-    const float rstd = rsqrtf(var + eps);
-    const float xh = d * rstd;
-    float du = on ? to_f(dy[(size_t)r * C + c]) : 0.f;
-    if (act == 1) du *= gelu_grad(xh * g + bt);
-    dg += du * xh;
-    db += du;
-    const float a = du * g;
-    const float m1 = block_sum(a, red) / C;
-    const float m2 = block_sum(a * xh, red) / C;
-    if (on) dx[(size_t)r * C + c] = from_f<T>(rstd * (a - m1 - xh * m2));
+  extern __shared__ float red_s[];                 // [4 waves][2][C] cross-wave sums of dgamma / dbeta
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nc = (C + 63) >> 6;
+  float g[NCMAX], bt[NCMAX], dg[NCMAX], db[NCMAX];
+#pragma unroll
+  for (int i = 0; i < NCMAX; ++i) {
+    const int c = lane + 64 * i;
+    g[i] = (i < nc && c < C) ? gamma[c] : 0.f;
+    bt[i] = (i < nc && c < C) ? beta[c] : 0.f;
+    dg[i] = 0.f; db[i] = 0.f;
   }
-  if (on) {
-    part[(size_t)blockIdx.x * 2 * C + c] = dg;
-    part[(size_t)blockIdx.x * 2 * C + C + c] = db;
+  const int r0 = blockIdx.x * rows_per_wg;
+  for (int r = r0 + wave; r < r0 + rows_per_wg && r < rows; r += 4) {
+    float v[NCMAX], a[NCMAX], sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCMAX; ++i) {
+      const int c = lane + 64 * i;
+      v[i] = (i < nc && c < C) ? to_f(x[(size_t)r * C + c]) : 0.f;
+      a[i] = (i < nc && c < C) ? to_f(dy[(size_t)r * C + c]) : 0.f;
+      sum += v[i];
+    }
+    const float mean = wave_sum(sum) / C;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCMAX; ++i) {
+      const int c = lane + 64 * i;
+      v[i] = (i < nc && c < C) ? v[i] - mean : 0.f;
+      sq += v[i] * v[i];
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / C + eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCMAX; ++i) {
+      const float xh = v[i] * rstd;
+      float du = a[i];
+      if (act == 1) du *= gelu_grad(xh * g[i] + bt[i]);
+      dg[i] += du * xh;
+      db[i] += du;
+      v[i] = xh;
+      a[i] = du * g[i];
+      s1 += a[i];
+      s2 += a[i] * xh;
+    }
+    const float m1 = wave_sum(s1) / C, m2 = wave_sum(s2) / C;
+#pragma unroll
+    for (int i = 0; i < NCMAX; ++i) {
+      const int c = lane + 64 * i;
+      if (i < nc && c < C) dx[(size_t)r * C + c] = from_f<T>(rstd * (a[i] - m1 - v[i] * m2));
+    }
+  }
+  // combine the 4 waves' per-channel sums in a fixed order, one partial row per workgroup
+#pragma unroll
+  for (int i = 0; i < NCMAX; ++i) {
+    const int c = lane + 64 * i;
+    if (i < nc && c < C) { red_s[(wave * 2 + 0) * C + c] = dg[i]; red_s[(wave * 2 + 1) * C + c] = db[i]; }
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < 2 * C; j += 256) {
+    const int which = j / C, c = j % C;
+    part[(size_t)blockIdx.x * 2 * C + j] = red_s[(0 * 2 + which) * C + c] + red_s[(1 * 2 + which) * C + c] +
+                                           red_s[(2 * 2 + which) * C + c] + red_s[(3 * 2 + which) * C + c];
   }
 }
 
-// out[j] (+)= sum_w part[w * stride + j], j < n.  256 threads = 64 columns x 4 slices of w; the four
-// slice sums are combined in a fixed order => reproducible.
-__global__ __launch_bounds__(256) void reduce_partials(const float* __restrict__ part, float* __restrict__ out, int n, int W,
-                                                       int stride, int accumulate) {
-  __shared__ float sm[4][64];
+// out[j] (+)= sum_w part[w * stride + j], j < n.  1024 threads = 64 columns x 16 slices of w; the slice sums
+// are combined in a fixed order => reproducible.
+__global__ __launch_bounds__(1024) void reduce_partials(const float* __restrict__ part, float* __restrict__ out, int n, int W,
+                                                        int stride, int accumulate) {
+  __shared__ float sm[16][64];
   const int col = threadIdx.x & 63, slice = threadIdx.x >> 6;
   const int j = blockIdx.x * 64 + col;
   float s = 0.f;
   if (j < n)
-    for (int w = slice; w < W; w += 4) s += part[(size_t)w * stride + j];
+    for (int w = slice; w < W; w += 16) s += part[(size_t)w * stride + j];
   sm[slice][col] = s;
   __syncthreads();
   if (slice == 0 && j < n) {
-    float t = (accumulate ? out[j] : 0.f) + sm[0][col];
-    t += sm[1][col]; t += sm[2][col]; t += sm[3][col];
+    float t = accumulate ? out[j] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sm[k][col];
     out[j] = t;
   }
 }
@@ -180,7 +248,7 @@ int pick_rows_per_wg(int rows, int max_wgs = 512) {
   if (wgs < 1) wgs = 1;
   return (rows + wgs - 1) / wgs;
 }
-constexpr int kBwdWgs = 96;
+constexpr int kBwdWgs = 384;
 
 }  // namespace
 
@@ -195,7 +263,7 @@ extern "C" int vits_ln_act_cl(int dtype, const void* x, const float* gamma, cons
                               int rows, int c, float eps, int act, void* stream) {
   if (!x || !gamma || !beta || !y || rows <= 0 || c <= 0) return VITS_E_BADARG;
   if (c > 1024 || act < 0 || act > 1) return VITS_E_UNSUPPORTED;
-  const int threads = ((c + 63) / 64) * 64, rpw = pick_rows_per_wg(rows), wgs = (rows + rpw - 1) / rpw;
+  const int threads = 256, rpw = pick_rows_per_wg(rows, 1024), wgs = (rows + rpw - 1) / rpw;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == VITS_DT_BF16)
     hipLaunchKernelGGL(ln_act_fwd<__bf16>, dim3(wgs), dim3(threads), 0, s, (const __bf16*)x, gamma, beta, (const __bf16*)res, (__bf16*)y, rows, c, eps, act, rpw);
@@ -211,17 +279,18 @@ extern "C" int vits_ln_act_cl_bwd(int dtype, const void* x, const float* gamma, 
   if (!x || !gamma || !beta || !dy || !dx || !dgamma || !dbeta || !workspace || rows <= 0 || c <= 0) return VITS_E_BADARG;
   if (c > 1024 || act < 0 || act > 1) return VITS_E_UNSUPPORTED;
   if (workspace_bytes < vits_rowops_workspace(rows, c, 1)) return VITS_E_BADARG;
-  const int threads = ((c + 63) / 64) * 64, rpw = pick_rows_per_wg(rows, kBwdWgs), wgs = (rows + rpw - 1) / rpw;
+  const int threads = 256, rpw = pick_rows_per_wg(rows, kBwdWgs), wgs = (rows + rpw - 1) / rpw;
+  const size_t lds = (size_t)8 * c * sizeof(float);
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* part = static_cast<float*>(workspace);
   if (dtype == VITS_DT_BF16)
-    hipLaunchKernelGGL(ln_act_bwd<__bf16>, dim3(wgs), dim3(threads), 0, s, (const __bf16*)x, gamma, beta, (const __bf16*)dy, (__bf16*)dx, part, rows, c, eps, act, rpw);
+    hipLaunchKernelGGL(ln_act_bwd<__bf16>, dim3(wgs), dim3(threads), lds, s, (const __bf16*)x, gamma, beta, (const __bf16*)dy, (__bf16*)dx, part, rows, c, eps, act, rpw);
   else if (dtype == VITS_DT_F32)
-    hipLaunchKernelGGL(ln_act_bwd<float>, dim3(wgs), dim3(threads), 0, s, (const float*)x, gamma, beta, (const float*)dy, (float*)dx, part, rows, c, eps, act, rpw);
+    hipLaunchKernelGGL(ln_act_bwd<float>, dim3(wgs), dim3(threads), lds, s, (const float*)x, gamma, beta, (const float*)dy, (float*)dx, part, rows, c, eps, act, rpw);
   else return VITS_E_UNSUPPORTED;
   // partials are [wg][2][c]: dgamma then dbeta
-  hipLaunchKernelGGL(reduce_partials, dim3((c + 63) / 64), dim3(256), 0, s, part, dgamma, c, wgs, 2 * c, accumulate);
-  hipLaunchKernelGGL(reduce_partials, dim3((c + 63) / 64), dim3(256), 0, s, part + c, dbeta, c, wgs, 2 * c, accumulate);
+  hipLaunchKernelGGL(reduce_partials, dim3((c + 63) / 64), dim3(1024), 0, s, part, dgamma, c, wgs, 2 * c, accumulate);
+  hipLaunchKernelGGL(reduce_partials, dim3((c + 63) / 64), dim3(1024), 0, s, part + c, dbeta, c, wgs, 2 * c, accumulate);
   return vits::check_launch("vits_ln_act_cl_bwd");
 }
 
@@ -255,7 +324,7 @@ extern "C" int vits_dwconv_cl_bwd(int dtype, const void* x, const float* w, cons
     hipLaunchKernelGGL(dwconv_bwd<float>, dim3(wgs), dim3(threads), 0, s, (const float*)x, w, lengths, (const float*)dy, (float*)dx, part, b, t, c, k, dil, rpw);
   else return VITS_E_UNSUPPORTED;
   // partial rows are [(k+1)*c]: first k*c = dw[c][k], then c = dbias
-  hipLaunchKernelGGL(reduce_partials, dim3((k * c + 63) / 64), dim3(256), 0, s, part, dw, k * c, wgs, (k + 1) * c, accumulate);
-  hipLaunchKernelGGL(reduce_partials, dim3((c + 63) / 64), dim3(256), 0, s, part + (size_t)k * c, dbias, c, wgs, (k + 1) * c, accumulate);
+  hipLaunchKernelGGL(reduce_partials, dim3((k * c + 63) / 64), dim3(1024), 0, s, part, dw, k * c, wgs, (k + 1) * c, accumulate);
+  hipLaunchKernelGGL(reduce_partials, dim3((c + 63) / 64), dim3(1024), 0, s, part + (size_t)k * c, dbias, c, wgs, (k + 1) * c, accumulate);
   return vits::check_launch("vits_dwconv_cl_bwd");
 }

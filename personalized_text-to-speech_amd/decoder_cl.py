@@ -167,8 +167,12 @@ class DecoderFn(torch.autograd.Function):
         def flip_t(r):                       # data-gradient operand of weight slot r
             return WA.bwd_operand(R[r])
 
-        def WGo(x, dy, k, slot, **kw):       # weight gradient written into the arena's dw region when there is one
-            return WG(x, dy, k, out=R[slot].dw, **kw)
+        def WGo(x, dy, k, slot, bias_slot=None, **kw):     # weight gradient into the arena's dw region when there is one;
+            db = None                                      # the bias gradient (column sums of dy) rides in the same launch
+            if bias_slot is not None:
+                db = torch.empty(dy.size(2), dtype=torch.float32, device=dy.device)
+                grads[bias_slot] = db
+            return WG(x, dy, k, out=R[slot].dw, dbias=db, **kw)
 
         def bias_grad(d):
             return d.sum((0, 1), dtype=torch.float32)
@@ -196,11 +200,9 @@ class DecoderFn(torch.autograd.Function):
                         t1 = saved.pop()
                         r_in = saved.pop()
                         p2, p1 = (rk - 1) // 2, (rk * d - d) // 2
-                        grads[i2[0]] = WGo(t1, dr, rk, i2[0], pad=p2, in_slope=0.1)
-                        grads[i2[1]] = bias_grad(dr)
+                        grads[i2[0]] = WGo(t1, dr, rk, i2[0], i2[1], pad=p2, in_slope=0.1)
                         dt1 = C(dr, flip_t(i2[0]), None, mg_src=t1, pad=p2, mg_slope=0.1)
-                        grads[i1[0]] = WGo(r_in, dt1, rk, i1[0], dil=d, pad=p1, in_slope=0.1)
-                        grads[i1[1]] = bias_grad(dt1)
+                        grads[i1[0]] = WGo(r_in, dt1, rk, i1[0], i1[1], dil=d, pad=p1, in_slope=0.1)
                         if first:     # gradient wrt the stage input x: accumulated over the parallel resblocks
                             _dgrad_res(dt1, flip_t(i1[0]), r_in, dr, d, p1, out=dx, accum=j < plan.num_kernels - 1)
                             dr = None
@@ -209,8 +211,7 @@ class DecoderFn(torch.autograd.Function):
                     else:
                         r_in = saved.pop()
                         p1 = (rk * d - d) // 2
-                        grads[i1[0]] = WGo(r_in, dr, rk, i1[0], dil=d, pad=p1, in_slope=0.1)
-                        grads[i1[1]] = bias_grad(dr)
+                        grads[i1[0]] = WGo(r_in, dr, rk, i1[0], i1[1], dil=d, pad=p1, in_slope=0.1)
                         if first:
                             _dgrad_res(dr, flip_t(i1[0]), r_in, dr, d, p1, out=dx, accum=j < plan.num_kernels - 1)
                             dr = None
@@ -225,8 +226,7 @@ class DecoderFn(torch.autograd.Function):
             dh = C(dp, flip_t(iu[0]), None, mg_src=h_prev, mg_slope=0.1)
         z = saved.pop()
         i_pre = idx["pre"]
-        grads[i_pre[0]] = WGo(z, dh, 7, i_pre[0], pad=3)
-        grads[i_pre[1]] = bias_grad(dh)
+        grads[i_pre[0]] = WGo(z, dh, 7, i_pre[0], i_pre[1], pad=3)
         dz = C(dh, flip_t(i_pre[0]), None, pad=3)
         dcond = dh.sum(1, dtype=torch.float32) if ctx.has_cond else None
         return (None, None, dz, dcond, *grads)

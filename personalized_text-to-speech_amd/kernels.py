@@ -239,8 +239,9 @@ def workspace(nbytes, device):
     return buf
 
 
-def conv1d_cl_wgrad_raw(x, dy, k, lengths=None, dil=1, pad=0, stride=1, in_slope=1.0, flags=0, out=None):
-    """dW [k, c_out, c_in] float32 of conv1d_cl_raw(x, w, ...) given dy [b, t_out, c_out]."""
+def conv1d_cl_wgrad_raw(x, dy, k, lengths=None, dil=1, pad=0, stride=1, in_slope=1.0, flags=0, out=None, dbias=None):
+    """dW [k, c_out, c_in] float32 of conv1d_cl_raw(x, w, ...) given dy [b, t_out, c_out]; optionally the bias
+    gradient (column sums of dy) into `dbias` float32 [c_out] in the same launch."""
     _lib.require_cuda(x, dy)
     assert x.dtype == dy.dtype
     b, t, c_in = x.shape
@@ -257,7 +258,9 @@ def conv1d_cl_wgrad_raw(x, dy, k, lengths=None, dil=1, pad=0, stride=1, in_slope
     d = _lib.WgradDesc(dtype=_DT[x.dtype], b=b, t=t, c_in=c_in, c_out=c_out, k=k, dil=dil, pad=pad, stride=stride, flags=int(flags),
                        ldx=_rows(x, "x"), lddy=_rows(dy, "dy"), in_slope=float(in_slope), reserved=0.0,
                        x=x.data_ptr(), dy=dy.data_ptr(), dw=out.data_ptr(), workspace=ws.data_ptr(), workspace_bytes=ws.numel(),
-                       lengths=None if lengths is None else lengths.data_ptr())
+                       lengths=None if lengths is None else lengths.data_ptr(),
+                       dbias=None if dbias is None else dbias.data_ptr())
+    assert dbias is None or (dbias.dtype == torch.float32 and dbias.is_contiguous() and dbias.numel() == c_out)
     import ctypes
     e0 = _lib.timer.start("vits_conv1d_cl_wgrad")
     rc = L.vits_conv1d_cl_wgrad(ctypes.addressof(d), _lib.stream_ptr())

@@ -71,10 +71,13 @@ class ConvCLFn(torch.autograd.Function):
             t = dy.size(1)
             dy = dy * (torch.arange(t, device=dy.device)[None, :, None] < ctx.lengths[:, None, None])
         dw = db = None
+        want_db = ctx.has_bias and ctx.needs_input_grad[3]
         if ctx.needs_input_grad[2]:
+            if want_db and dy.size(2) % 8 == 0:
+                db = torch.empty(dy.size(2), dtype=torch.float32, device=dy.device)
             dw = K.conv1d_cl_wgrad_raw(xd, dy, k, lengths=ctx.lengths, dil=dil, pad=pad, stride=stride, in_slope=in_slope,
-                                       flags=K.CONV_MASK_IN if mask_in else 0, out=R.dw)
-        if ctx.has_bias and ctx.needs_input_grad[3]:
+                                       flags=K.CONV_MASK_IN if mask_in else 0, out=R.dw, dbias=db)
+        if want_db and db is None:
             db = dy.sum((0, 1), dtype=torch.float32)
         dx = None
         if ctx.needs_input_grad[1]:
@@ -189,7 +192,6 @@ class WNFn(torch.autograd.Function):
         t = d_out.size(1)
         rowmask = (torch.arange(t, device=d_out.device)[None, :, None] < lengths[:, None, None])
         d_o = (d_out * rowmask).to(dtype).contiguous()          # d(output * x_mask)
-        s_o = d_o.sum((0, 1), dtype=torch.float32)
         dcond = [] if ctx.has_cond else None
         d_h = None
         for i in reversed(range(L)):
@@ -197,13 +199,16 @@ class WNFn(torch.autograd.Function):
             r_in, r_res, r_skip = R[5 * i], R[5 * i + 2], R[5 * i + 3]
             d = plan.dils[i]
             pad = (k * d - d) // 2
-            grads[5 * i + 3] = WG(acts, d_o, 1, out=r_skip.dw)
             if i == L - 1:
-                grads[5 * i + 4] = s_o
+                db_rs = torch.empty(H, dtype=torch.float32, device=d_o.device)
+                grads[5 * i + 3] = WG(acts, d_o, 1, out=r_skip.dw, dbias=db_rs)
+                grads[5 * i + 4] = db_rs
                 d_pre = C(d_o, WA.bwd_operand(r_skip), None, mg_src=pre, lengths=lengths, flags=K.CONV_GATE_BWD | K.CONV_MASK_OUT, gate_h=H)
             else:
-                grads[5 * i + 2] = WG(acts, d_h, 1, out=r_res.dw)
-                grads[5 * i + 4] = torch.cat([d_h.sum((0, 1), dtype=torch.float32), s_o])
+                db_rs = torch.empty(2 * H, dtype=torch.float32, device=d_o.device)
+                grads[5 * i + 3] = WG(acts, d_o, 1, out=r_skip.dw, dbias=db_rs[H:])
+                grads[5 * i + 2] = WG(acts, d_h, 1, out=r_res.dw, dbias=db_rs[:H])
+                grads[5 * i + 4] = db_rs
                 # partial d(acts) from the residual branch, held in the left half of a 2H-wide buffer so that
                 # its row pitch equals that of the GATE_BWD output (the kernel shares ldy between y, res, mg_src)
                 tmp = torch.empty_like(pre)[..., :H]

@@ -62,7 +62,7 @@ def conv1d_cl_raw(x, w, bias=None, bias_b=None, res=None, mg_src=None, out=None,
     return v
 
 
-def conv1d_cl_wgrad_raw(x, dy, k, lengths=None, dil=1, pad=0, stride=1, in_slope=1.0, flags=0, out=None):
+def conv1d_cl_wgrad_raw(x, dy, k, lengths=None, dil=1, pad=0, stride=1, in_slope=1.0, flags=0, out=None, dbias=None):
     b, t, c_in = x.shape
     c_out = dy.shape[2]
     w = torch.zeros(k, c_out, c_in, device=x.device, requires_grad=True)
@@ -76,6 +76,11 @@ def conv1d_cl_wgrad_raw(x, dy, k, lengths=None, dil=1, pad=0, stride=1, in_slope
     with torch.enable_grad():
         y = F.conv1d(xf.transpose(1, 2), w.permute(1, 2, 0), None, stride, pad, dil).transpose(1, 2)
         (g,) = torch.autograd.grad(y, w, dyf)
+    if dbias is not None:
+        if flags & 8:
+            dbias.add_(dyf.sum((0, 1)))
+        else:
+            dbias.copy_(dyf.sum((0, 1)))
     if out is not None:
         if flags & 8:
             out.add_(g)

@@ -114,8 +114,11 @@ def test_weight_gradient(pkg, case, dtype, tol):
     # plain
     y = ref_conv(x, w, None, dil, pad, 0.1)
     (want,) = torch.autograd.grad(y, w, dy.float())
-    got = K.conv1d_cl_wgrad_raw(x, dy, k, dil=dil, pad=pad, in_slope=0.1)
+    db = torch.empty(co, device=DEV) if co % 8 == 0 else None
+    got = K.conv1d_cl_wgrad_raw(x, dy, k, dil=dil, pad=pad, in_slope=0.1, dbias=db)
     assert rel(got, want) < tol
+    if db is not None:                                   # bias gradient from the same launch
+        assert rel(db, dy.float().sum((0, 1))) < 1e-5
     # masked input and output rows, accumulated onto an existing gradient
     y = ref_conv((x.float() * mask).to(dtype), w, None, dil, pad, 1.0) * mask
     (want,) = torch.autograd.grad(y, w, dy.float())

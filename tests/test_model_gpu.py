@@ -116,20 +116,22 @@ def test_mel_of_generated_audio_matches_oracle(pkg):
     assert rel_err(ya.grad, yb.grad) < 1e-3
 
 
-def test_period_discriminator_hip_path_matches_rocm_path(pkg):
-    """The channels-last HIP implementation of DiscriminatorP (off by default) against the MIOpen path."""
+def test_period_discriminator_hip_path(pkg):
+    """The channels-last HIP implementation of DiscriminatorP (off by default) against the oracle on the CPU
+    (MIOpen's fp32 solvers are find-mode dependent and too noisy to serve as the yardstick for gradients)."""
+    from oracle import vits_torch as O
     torch.manual_seed(4)
     d = pkg.models.DiscriminatorP(3).cuda()
-    x = (torch.rand(4, 1, 8192, device="cuda:0") * 2 - 1)
-    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    sd = {"d." + k: v.detach().cpu().clone().requires_grad_(True) for k, v in d.state_dict().items()}
+    x = (torch.rand(4, 1, 4096) * 2 - 1)
+    xa, xb = x.cuda().requires_grad_(True), x.clone().requires_grad_(True)
     la, fa = d.forward_hip(xa)
-    lb, fb = d.forward_rocm(xb)
-    assert rel_err(la, lb) < 1e-3
+    lb, fb = O.disc_p(sd, "d", xb, 3)
+    assert rel_err(la, lb) < 1e-4
     for a, b in zip(fa, fb):
-        assert a.shape == b.shape and rel_err(a, b) < 1e-3
-    la.pow(2).sum().backward(); ga = {k: p.grad.clone() for k, p in d.named_parameters()}
-    d.zero_grad()
+        assert a.shape == b.shape and rel_err(a, b) < 1e-4
+    la.pow(2).sum().backward()
     lb.pow(2).sum().backward()
-    assert rel_err(xa.grad, xb.grad) < 2e-3
+    assert rel_err(xa.grad, xb.grad) < 1e-3
     for k, p in d.named_parameters():
-        assert rel_err(ga[k], p.grad) < 2e-3, k
+        assert rel_err(p.grad, sd["d." + k].grad) < 1e-3, k
