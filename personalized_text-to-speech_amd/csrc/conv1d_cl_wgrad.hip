@@ -66,14 +66,16 @@ constexpr int XV_MAX = 10;     // ... of the X tile (xrows*VPR <= 256*XV_MAX, el
 // One workgroup = one 64(co) x 64(ci) tile x one GROUP of at most KT taps x one split of the (b,t) reduction.
 // Splitting the taps over workgroups multiplies the parallelism of large-k layers without any extra slab
 // traffic (the tiles of x and dy are re-read from L2), and keeps the accumulators at KT*16 registers.
-template <typename T, int KT>
+// SMALL = true: c_out <= 32 and c_in <= 32 (last decoder stage): the four waves share the single 32x32 block
+// and split each chunk's 128 rows among themselves; their accumulators are summed through LDS at the end.
+template <typename T, int KT, bool SMALL>
 __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int V = 16 / sizeof(T);
   constexpr int PITCH = Pitch<T>::value;
   constexpr int VPR = CT / V;                 // 16-byte vectors per tile row
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wi = wave >> 1, wj = wave & 1;
+  const int wi = SMALL ? 0 : (wave >> 1), wj = SMALL ? 0 : (wave & 1);
   const int r = lane & 31, h = lane >> 5;
   const int n_ci_tiles = (a.Cin + CT - 1) / CT;
   const int co0 = blockIdx.y * CT, ci0 = (blockIdx.z % n_ci_tiles) * CT;
@@ -181,8 +183,9 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
       const int colA = (wi * 32 + 16 * (g & 1) + 4 * p) * 2;
       const int colB = (wj * 32 + 16 * (g & 1) + 4 * p) * 2;
       const int rowk = 8 * (g >> 1) + q;
+      const int s_lo = SMALL ? wave * (TK / 64) : 0, s_hi = SMALL ? (wave + 1) * (TK / 64) : TK / 16;
 #pragma unroll 2
-      for (int s = 0; s < TK / 16; ++s) {
+      for (int s = s_lo; s < s_hi; ++s) {
         union { s16x4 half[2]; bf16x8 v; } fa;
 #pragma unroll
         for (int rd = 0; rd < 2; ++rd) {
@@ -208,8 +211,9 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
       const float* dA = reinterpret_cast<const float*>(ldsD) + wi * 32 + r;
       const float* xB = reinterpret_cast<const float*>(ldsX) + wj * 32 + r;
       constexpr int PF = PITCH / 4;
+      const int f_lo = SMALL ? wave * (TK / 8) : 0, f_hi = SMALL ? (wave + 1) * (TK / 8) : TK / 2;
 #pragma unroll 4
-      for (int s = 0; s < TK / 2; ++s) {
+      for (int s = f_lo; s < f_hi; ++s) {
         const float av = dA[(2 * s + h) * PF];
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
@@ -236,10 +240,29 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
       a.partial_db[(size_t)blockIdx.x * a.Cout + co0 + tid] = red[tid] + red[tid + 64] + red[tid + 128] + red[tid + 192];
     __syncthreads();
   }
+  if constexpr (SMALL) {                                  // sum the four waves' accumulators (fixed order) into wave 0
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);          // [3 waves][KT][16][64] floats <= 48 KB
+    if (wave > 0) {
+#pragma unroll
+      for (int k = 0; k < KT; ++k)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[(((wave - 1) * KT + k) * 16 + i) * 64 + lane] = acc[k][i];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int w = 0; w < 3; ++w)
+#pragma unroll
+        for (int k = 0; k < KT; ++k)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[k][i] += red[((w * KT + k) * 16 + i) * 64 + lane];
+    }
+  }
   // slab of this split: partial[split][tap][co][ci]
   float* P = a.partial + (size_t)blockIdx.x * a.K * a.Cout * a.Cin;
   const int ci = ci0 + wj * 32 + r;
-  if (ci < a.Cin) {
+  if (ci < a.Cin && (!SMALL || wave == 0)) {
 #pragma unroll
     for (int k = 0; k < KT; ++k)
       if (k < ntap) {
@@ -273,9 +296,10 @@ int pick_splits(int b, int t_out, int c_in, int c_out, int k) {
   const int groups = vits::ceil_div(c_out, CT) * vits::ceil_div(c_in, CT) * vits::ceil_div(k, kt);
   const int chunks = b * vits::ceil_div(t_out, TK);
   int s = vits::ceil_div(768, groups);
-  const double io_elems = (double)b * t_out * (c_in + c_out);
-  const double dw_elems = (double)k * c_out * c_in;
-  const int s_traffic = (int)(io_elems / dw_elems) + 1;
+  const double io_elems = (double)b * t_out * (c_in + c_out);          // read once, 2 B (bf16) each
+  const double dw_elems = (double)k * c_out * c_in;                    // each split writes + re-reads it in fp32: 8 B each
+  const int s_traffic = (int)(io_elems / dw_elems) + 1;                // slab bytes <= 4x activation bytes (measured: for these
+                                                                       // small layers parallelism beats the extra slab traffic)
   if (s > s_traffic) s = s_traffic;
   if (s > 64) s = 64;
   if (s > chunks) s = chunks;
@@ -283,12 +307,13 @@ int pick_splits(int b, int t_out, int c_in, int c_out, int k) {
   return s;
 }
 
-template <typename T, int KT>
+template <typename T, int KT, bool SMALL>
 int launch(const WgradArgs& a, hipStream_t s) {
   constexpr int PITCH = Pitch<T>::value;
-  const size_t lds = (size_t)(TK + (TK - 1) * a.stride + (KT - 1) * a.dil + 1) * PITCH;
+  size_t lds = (size_t)(TK + (TK - 1) * a.stride + (KT - 1) * a.dil + 1) * PITCH;
+  if (SMALL && lds < (size_t)3 * KT * 16 * 64 * 4) lds = (size_t)3 * KT * 16 * 64 * 4;
   if (lds > (size_t)vits::kLdsBytesMax) return VITS_E_UNSUPPORTED;
-  auto kern = wgrad_kernel<T, KT>;
+  auto kern = wgrad_kernel<T, KT, SMALL>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return vits::note_hip_error(e, "vits_conv1d_cl_wgrad/attr");
@@ -300,11 +325,12 @@ int launch(const WgradArgs& a, hipStream_t s) {
 
 template <typename T>
 int dispatch_k(const WgradArgs& a, hipStream_t s) {
+  const bool small = a.Cout <= 32 && a.Cin <= 32;
   switch (taps_per_group(a.K)) {
-    case 1: return launch<T, 1>(a, s);
-    case 2: return launch<T, 2>(a, s);
-    case 3: return launch<T, 3>(a, s);
-    default: return launch<T, 4>(a, s);
+    case 1: return small ? launch<T, 1, true>(a, s) : launch<T, 1, false>(a, s);
+    case 2: return small ? launch<T, 2, true>(a, s) : launch<T, 2, false>(a, s);
+    case 3: return small ? launch<T, 3, true>(a, s) : launch<T, 3, false>(a, s);
+    default: return small ? launch<T, 4, true>(a, s) : launch<T, 4, false>(a, s);
   }
 }
 
