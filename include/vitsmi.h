@@ -118,6 +118,10 @@ typedef struct vits_conv_desc {
   int32_t ldy;              /* row pitch of y, res and mg_src                                             */
   int32_t ldy2;             /* row pitch of y2                                                            */
   int32_t gate_h;           /* H of the gate flags                                                        */
+  int32_t ldw;              /* row pitch of w (>= c_in; 0 = dense): w rows may be channel slices            */
+  int32_t reserved0;
+  int64_t w_batch_stride;   /* elements between the operands of consecutive batch items; 0 = one shared w:
+                               with k = 1 this makes the call a batched product Y[b] = X[b] . W[b]^T (attention) */
   float in_slope, mg_slope, out_scale, out_slope;
   const void* x;  const void* w;  const float* bias;  const float* bias_b;
   const void* res;  const void* mg_src;  void* y;  void* y2;  const int32_t* lengths;
@@ -240,6 +244,26 @@ int vits_rq_spline(int h_dtype, const float* x, const void* h, int ldh, float hs
                    float* y, float* logabsdet, int n, void* stream);
 int vits_rq_spline_bwd(int h_dtype, const float* x, const void* h, int ldh, float hscale, int inverse, float tail_bound,
                        const float* gy, const float* glogabsdet, float* gx, void* gh, int n, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Windowed relative-position attention: the row kernels between the matrix products.
+ *
+ * Replaces: attentions.MultiHeadAttention.attention (attentions.py:150-182) — the scale, the relative-key
+ *           logits' skew (:214-229), masked_fill(-1e4), softmax, attention dropout, and the abs->rel skew of
+ *           the probabilities (:231-243) — and their autograd.  The products QK^T, Q E_k^T, P V, P_band E_v and
+ *           all their gradients are vits_conv1d_cl calls with k = 1 and per-item operands (w_batch_stride).
+ *   s  [b][t][ld]  raw scores Q K^T of ONE head (ld >= t, pad columns ignored / written as 0);
+ *   r  [b][t][16]  raw relative-key logits Q E_k^T (columns 0..2w used) or NULL;
+ *   keep [b][t][ld] dropout keep-scale (0 or 1/(1-p)) or NULL;  lengths int32[b] or NULL;
+ *   p, pd [b][t][ld]  softmax and dropped softmax (pd may be NULL);  pband [b][t][16] = pd[i][i+m-w] or NULL.
+ *   backward: ds = d(raw scores), dsband [b][t][16] = d(raw relative-key logits), from dpd, dpband.
+ *   t <= 1024, 2*window+1 <= 16.
+ * ------------------------------------------------------------------------------------------ */
+int vits_relsoftmax(int dtype, const void* s, const void* r, const void* keep, const int32_t* lengths, void* p, void* pd,
+                    void* pband, int b, int t, int ld, int window, float scale, void* stream);
+int vits_relsoftmax_bwd(int dtype, const void* p, const void* dpd, const void* dpband, const void* keep,
+                        const int32_t* lengths, void* ds, void* dsband, int b, int t, int ld, int window, float scale,
+                        void* stream);
 
 #ifdef __cplusplus
 }

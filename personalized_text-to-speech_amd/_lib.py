@@ -10,7 +10,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvitsmi.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_int = ctypes.c_int
 c_void_p = ctypes.c_void_p
@@ -23,6 +23,8 @@ SIGNATURES = {
     "vits_abi_version": (c_int, []),
     "vits_last_error": (ctypes.c_char_p, []),
     "vits_mas_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "vits_relsoftmax": (c_int, [c_int] + [c_void_p] * 7 + [c_int] * 4 + [c_float, c_void_p]),
+    "vits_relsoftmax_bwd": (c_int, [c_int] + [c_void_p] * 7 + [c_int] * 4 + [c_float, c_void_p]),
     "vits_rq_spline": (c_int, [c_int, c_void_p, c_void_p, c_int, c_float, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p]),
     "vits_rq_spline_bwd": (c_int, [c_int, c_void_p, c_void_p, c_int, c_float, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "vits_rowops_workspace": (c_size_t, [c_int, c_int, c_int]),
@@ -42,7 +44,8 @@ SIGNATURES = {
 class ConvDesc(ctypes.Structure):
     """vits_conv_desc of include/vitsmi.h"""
     _fields_ = [(n, ctypes.c_int32) for n in ("dtype", "b", "t", "c_in", "c_out", "k", "dil", "pad", "stride", "flags",
-                                              "ldx", "ldy", "ldy2", "gate_h")] + \
+                                              "ldx", "ldy", "ldy2", "gate_h", "ldw", "reserved0")] + \
+               [("w_batch_stride", ctypes.c_int64)] + \
                [(n, c_float) for n in ("in_slope", "mg_slope", "out_scale", "out_slope")] + \
                [(n, c_void_p) for n in ("x", "w", "bias", "bias_b", "res", "mg_src", "y", "y2", "lengths")]
 

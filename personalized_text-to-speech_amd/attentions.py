@@ -83,9 +83,10 @@ class MultiHeadAttention(nn.Module):
         q = wn_cl.conv_cl(h, wn_cl.weight_of(self.conv_q), self.conv_q.bias)
         k = wn_cl.conv_cl(h, wn_cl.weight_of(self.conv_k), self.conv_k.bias)
         v = wn_cl.conv_cl(h, wn_cl.weight_of(self.conv_v), self.conv_v.bias)
-        o, self.attn = K.rel_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), self.emb_rel_k, self.emb_rel_v,
-                                       attn_mask, self.n_heads, self.window_size, self.p_dropout, self.training)
-        return wn_cl.conv_cl(o.transpose(1, 2).contiguous(), wn_cl.weight_of(self.conv_o), self.conv_o.bias, res=res)
+        from . import attention_cl
+        o, self.attn = attention_cl.rel_attention_cl(q, k, v, self.emb_rel_k, self.emb_rel_v, lengths, self.n_heads,
+                                                     self.window_size, self.p_dropout, self.training, q.dtype)
+        return wn_cl.conv_cl(o, wn_cl.weight_of(self.conv_o), self.conv_o.bias, res=res)
 
 
 class FFN(nn.Module):

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(kThreads) void conv1d_cl_kernel(ConvArgs args) {
   unsigned char* ldsW = smem + (size_t)xrows * PITCH;
 
   const T* X = static_cast<const T*>(a.x) + (size_t)b * a.t * a.ldx;
-  const T* W = static_cast<const T*>(a.w);
+  const T* W = static_cast<const T*>(a.w) + (size_t)b * a.w_batch_stride;     // per-item operand (attention products) or shared weights
   const int len = (a.lengths != nullptr) ? a.lengths[b] : a.t;
   const int t_in_hi = (a.flags & VITS_CONV_MASK_IN) ? (len < a.t ? len : a.t) : a.t;
 
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(kThreads) void conv1d_cl_kernel(ConvArgs args) {
       if (idx < ntap * TN * 8) {
         const int ch = idx & 7, col = (idx >> 3) % TN, tl = (idx >> 3) / TN;
         const int co = col_to_co(col), ci = ci0 + ch * V;
-        if (co >= 0 && ci < a.c_in) v = *reinterpret_cast<const u32x4*>(W + ((size_t)(tg + tl) * a.c_out + co) * a.c_in + ci);
+        if (co >= 0 && ci < a.c_in) v = *reinterpret_cast<const u32x4*>(W + ((size_t)(tg + tl) * a.c_out + co) * a.ldw + ci);
       }
       wr[i] = v;
     }
@@ -356,15 +356,17 @@ extern "C" int vits_conv1d_cl(const vits_conv_desc* desc, void* stream) {
   if (gate && (d.gate_h <= 0 || d.c_out != 2 * d.gate_h)) return VITS_E_BADARG;
   if (gate_bwd && (d.gate_h != d.c_out || !d.mg_src)) return VITS_E_BADARG;
   if (d.ldx <= 0) d.ldx = d.c_in;
+  if (d.ldw <= 0) d.ldw = d.c_in;
+  if (d.w_batch_stride < 0) return VITS_E_BADARG;
   if (d.ldy <= 0) d.ldy = gate ? d.gate_h : (gate_bwd ? 2 * d.gate_h : d.c_out);
   if (d.ldy2 <= 0) d.ldy2 = d.c_out;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (d.dtype == VITS_DT_BF16) {
-    if (d.c_in % 8 != 0 || d.ldx % 8 != 0) return VITS_E_UNSUPPORTED;
+    if (d.c_in % 8 != 0 || d.ldx % 8 != 0 || d.ldw % 8 != 0 || d.w_batch_stride % 8 != 0) return VITS_E_UNSUPPORTED;
     return dispatch_tile<__bf16>(d, t_out, s);
   }
   if (d.dtype == VITS_DT_F32) {
-    if (d.c_in % 4 != 0 || d.ldx % 4 != 0) return VITS_E_UNSUPPORTED;
+    if (d.c_in % 4 != 0 || d.ldx % 4 != 0 || d.ldw % 4 != 0 || d.w_batch_stride % 4 != 0) return VITS_E_UNSUPPORTED;
     return dispatch_tile<float>(d, t_out, s);
   }
   return VITS_E_UNSUPPORTED;

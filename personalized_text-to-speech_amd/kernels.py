@@ -22,7 +22,7 @@ BACKENDS = {
     "posterior encoder + flow (1x1 pre/post/proj, gated WN stacks; fwd+bwd)": "hip",
     "stochastic duration predictor (DDSConv: dwconv, LayerNorm+GELU, 1x1; spline; fwd+bwd)": "hip",
     "weight preparation (weight-norm, layouts, dtype; fwd+bwd)": "hip",
-    "text encoder (rel. attention, FFN, LayerNorm)": "rocm",
+    "text encoder (relative-position attention products + softmax row kernels, FFN, LayerNorm; fwd+bwd)": "hip",
     "stft (framed windowed DFT as an exact-fp32 MFMA product; fwd+bwd)": "hip",
     "discriminators (MIOpen, as BASELINE.json allows; HIP path for the period discriminators exists, off by default)": "rocm",
     "AdamW (torch fused multi-tensor)": "rocm",
@@ -191,9 +191,16 @@ def conv1d_cl_raw(x, w, bias=None, bias_b=None, res=None, mg_src=None, out=None,
     """Launch vits_conv1d_cl.  x [b,t,c_in], w [k,c_out,c_in] (tap-major) in the same dtype; see
     include/vitsmi.h for the fused prologue/epilogue.  Returns y (allocated unless `out` is given)."""
     _lib.require_cuda(x, w)
-    assert w.is_contiguous() and x.dtype == w.dtype and w.dim() == 3
+    assert x.dtype == w.dtype
     b, t, c_in = x.shape
-    k, c_out, c_in_w = w.shape
+    ldw, wbs = 0, 0
+    if w.dim() == 4:                       # per-item operand [b][k=1][c_out][c_in]: batched product Y[b] = X[b] . W[b]^T
+        assert w.size(0) == b and w.size(1) == 1 and w.stride(3) == 1
+        ldw, wbs = w.stride(2), w.stride(0)
+        k, c_out, c_in_w = 1, w.size(2), w.size(3)
+    else:
+        assert w.dim() == 3 and w.is_contiguous()
+        k, c_out, c_in_w = w.shape
     assert c_in_w == c_in, (tuple(x.shape), tuple(w.shape))
     t_out = (t + 2 * pad - dil * (k - 1) - 1) // stride + 1
     y_cols = gate_h if (flags & CONV_GATE) else (2 * gate_h if (flags & CONV_GATE_BWD) else c_out)
@@ -212,6 +219,7 @@ def conv1d_cl_raw(x, w, bias=None, bias_b=None, res=None, mg_src=None, out=None,
         flags |= CONV_OUT_LRELU
     d = _lib.ConvDesc(dtype=_DT[x.dtype], b=b, t=t, c_in=c_in, c_out=c_out, k=k, dil=dil, pad=pad, stride=stride, flags=int(flags),
                       ldx=_rows(x, "x"), ldy=ldy, ldy2=0 if out2 is None else _rows(out2, "out2"), gate_h=gate_h,
+                      ldw=ldw, reserved0=0, w_batch_stride=wbs,
                       in_slope=float(in_slope), mg_slope=float(mg_slope), out_scale=float(out_scale), out_slope=float(out_slope or 0.0),
                       x=x.data_ptr(), w=w.data_ptr(), bias=p(bias), bias_b=p(bias_b), res=p(res), mg_src=p(mg_src),
                       y=out.data_ptr(), y2=p(out2), lengths=p(lengths))

@@ -19,6 +19,7 @@ def emulated(pkg, monkeypatch):
     monkeypatch.setattr(dcl, "convt_fold", cl_emul.convt_fold)
     monkeypatch.setattr(dcl, "convt_unfold", cl_emul.convt_unfold)
     cl_emul.install_rowops(monkeypatch)
+    cl_emul.install_attention(monkeypatch)
     cl_emul.install_arena_emulation(monkeypatch)
     return pkg
 

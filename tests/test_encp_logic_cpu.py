@@ -13,6 +13,7 @@ def emulated(pkg, monkeypatch):
     monkeypatch.setattr(pkg.kernels, "conv1d_cl_raw", cl_emul.conv1d_cl_raw)
     monkeypatch.setattr(pkg.kernels, "conv1d_cl_wgrad_raw", cl_emul.conv1d_cl_wgrad_raw)
     cl_emul.install_rowops(monkeypatch)
+    cl_emul.install_attention(monkeypatch)
     return pkg
 
 
