@@ -177,7 +177,8 @@ int vits_convt_unfold_cl(int dtype, const void* dy, void* dp, int b, int t_in, i
  *           instead of ~8 small kernels per layer.
  *   entries  device array, one per (slice of a) convolution weight, sorted by row0:
  *     v        fp32 master weight in torch layout: Conv1d [c_out_total][c_in][k] (layout 0) or
- *              ConvTranspose1d [c_in_total][c_out][k] (layout 1);   g  weight_g [rows_total] or NULL;
+ *              ConvTranspose1d [c_in_total][c_out][k] (layout 1); layout 2 = Conv1d whose operand keeps the torch
+ *              layout (weight-norm + dtype only; consumed by a library convolution);  g  weight_g [rows_total] or NULL;
  *     row_lo   first weight-norm row of the parameter covered by this entry, n_rows rows are covered
  *              (layout 0: rows are output channels, c_out = n_rows; layout 1: rows are input channels);
  *     c_out_p / c_in_p   padded channel counts of the emitted operands (zero outside; pad areas are

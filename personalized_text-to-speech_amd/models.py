@@ -285,7 +285,10 @@ class _WNConv2dK1(nn.Module):
         return K.weight_norm(self.weight_v, self.weight_g).squeeze(-1)
 
     def forward(self, x):
-        w = K.weight_norm(self.weight_v, self.weight_g)
+        from . import weight_arena
+        w = weight_arena.handle_for(self, "torch")
+        if w is None:
+            w = K.weight_norm(self.weight_v, self.weight_g)
         return F.conv2d(x, w.to(x.dtype), self.bias.to(x.dtype), self.stride, self.padding)
 
 
@@ -394,10 +397,7 @@ class MultiPeriodDiscriminator(nn.Module):
         b = y.size(0)
         yy = torch.cat([y, y_hat], 0)
         y_d_rs, y_d_gs, fmap_rs, fmap_gs = [], [], [], []
-        if DiscriminatorP.use_hip:
-            with weight_arena.scope(self, MultiPeriodDiscriminator._arena_specs):
-                outs = [d(yy) for d in self.discriminators]
-        else:
+        with weight_arena.scope(self, MultiPeriodDiscriminator._arena_specs):
             outs = [d(yy) for d in self.discriminators]
         for out, fmap in outs:
             y_d_rs.append(out[:b]); y_d_gs.append(out[b:])
@@ -409,10 +409,12 @@ class MultiPeriodDiscriminator(nn.Module):
         from .weight_arena import Spec
         specs = []
         for d in net.discriminators:
-            if isinstance(d, DiscriminatorP):
+            if isinstance(d, DiscriminatorP) and DiscriminatorP.use_hip:
                 specs.append(Spec(d.convs[0], c_in_p=8))
                 specs += [Spec(l) for l in d.convs[1:]]
                 specs.append(Spec(d.conv_post, c_out_p=8))
+            else:           # library (MIOpen) convolutions: weight-norm + dtype for all layers in the same launch
+                specs += [Spec(l, "torch", torch_layout=True) for l in list(d.convs) + [d.conv_post]]
         return specs
 
 

@@ -25,8 +25,8 @@ _registry = {}             # handle.data_ptr() -> (arena, index)
 
 
 class Spec:
-    def __init__(self, module, part=None, row_lo=0, n_rows=None, c_out_p=None, c_in_p=None, transpose=False):
-        self.module, self.part, self.transpose = module, part, transpose
+    def __init__(self, module, part=None, row_lo=0, n_rows=None, c_out_p=None, c_in_p=None, transpose=False, torch_layout=False):
+        self.module, self.part, self.transpose, self.torch_layout = module, part, transpose, torch_layout
         has_g = hasattr(module, "weight_g")
         self.v = module.weight_v if has_g else module.weight
         self.g = module.weight_g if has_g else None
@@ -45,6 +45,9 @@ class Spec:
             self.c_out_p, self.c_in_p = c_out_p or self.c_out, c_in_p or d1
             self.numel = k * self.c_out_p * self.c_in_p
             self.fwd_shape, self.bwd_shape = (k, self.c_out_p, self.c_in_p), (k, self.c_in_p, self.c_out_p)
+            if torch_layout:                  # operand = weight-normed parameter in its own layout (library convolutions)
+                assert row_lo == 0 and n_rows is None and not c_out_p and not c_in_p
+                self.fwd_shape = self.bwd_shape = tuple(self.v.shape)
 
 
 class WeightArena:
@@ -73,7 +76,7 @@ class WeightArena:
             e.v, e.g = s.v.data_ptr(), (s.g.data_ptr() if s.g is not None else None)
             e.off, e.off_dv = off, self.p_off[pidx[id(s.v)]]
             e.off_dg = self.p_off[pidx[id(s.g)]] if s.g is not None else 0
-            e.layout, e.c_out, e.c_in, e.k = (1 if s.transpose else 0), s.c_out, s.c_in, s.k
+            e.layout, e.c_out, e.c_in, e.k = (2 if s.torch_layout else (1 if s.transpose else 0)), s.c_out, s.c_in, s.k
             e.c_out_p, e.c_in_p, e.row_lo, e.n_rows, e.row0 = s.c_out_p, s.c_in_p, s.row_lo, s.n_rows, row0
             row0 += s.n_rows
             off += (s.numel + 63) & ~63                         # keep every operand 128-byte aligned
@@ -86,7 +89,8 @@ class WeightArena:
         view = lambda buf, o, s, shape: buf[o:o + s.numel].view(shape)
         self.fwd = [view(self.w_fwd, o, s, s.fwd_shape) for o, s in zip(offs, specs)]
         self.bwd = [view(self.w_bwd, o, s, s.bwd_shape) for o, s in zip(offs, specs)]
-        self.handles = [view(self.handle, o, s, s.fwd_shape) for o, s in zip(offs, specs)]
+        # torch-layout operands are consumed by autograd-aware library ops: their handle is the operand itself
+        self.handles = [view(self.w_fwd if s.torch_layout else self.handle, o, s, s.fwd_shape) for o, s in zip(offs, specs)]
         self.dws = [view(self.dw, o, s, s.fwd_shape) for o, s in zip(offs, specs)]
         self.ptrs = [p.data_ptr() for p in self.params]
         for i, h in enumerate(self.handles):
@@ -115,7 +119,7 @@ class PrepFn(torch.autograd.Function):
             if d is None:
                 arena.dws[i].zero_()
             elif d.data_ptr() != arena.dws[i].data_ptr():
-                arena.dws[i].copy_(d)
+                arena.dws[i].copy_(d.reshape(arena.dws[i].shape))
         rc = _lib.lib().vits_weight_prep_bwd(arena.table.data_ptr(), arena.n, arena.total_rows, arena.dw.data_ptr(),
                                              arena.dparam.data_ptr(), _lib.stream_ptr())
         _lib.check(rc, "vits_weight_prep_bwd")

@@ -132,8 +132,10 @@ def weight_prep(arena):
     for s, f, bw in zip(arena.specs, arena.fwd, arena.bwd):
         v = s.v.detach().float()
         if s.g is not None:
-            v = v * (s.g.detach().float() / torch.linalg.vector_norm(v, 2, dim=(1, 2), keepdim=True))
-        if s.transpose:                                   # [c_in][c_out][k] -> [1][k*c_out][c_in_p]
+            v = v * (s.g.detach().float() / torch.linalg.vector_norm(v, 2, dim=tuple(range(1, v.dim())), keepdim=True))
+        if getattr(s, "torch_layout", False):
+            f.copy_(v.to(f.dtype))
+        elif s.transpose:                                   # [c_in][c_out][k] -> [1][k*c_out][c_in_p]
             w = v.permute(2, 1, 0).reshape(1, s.k * s.c_out, s.c_in)
             f.zero_(); f[:, :, : s.c_in] = w.to(f.dtype)
             bw.zero_(); bw[:, : s.c_in, :] = w.transpose(1, 2).to(bw.dtype)
@@ -150,7 +152,10 @@ def weight_prep_bwd(arena):
     pid = {id(p): i for i, p in enumerate(arena.params)}
     for s, dwv in zip(arena.specs, arena.dws):
         v = s.v.detach().float()
-        if s.transpose:
+        if getattr(s, "torch_layout", False):
+            dw = dwv.reshape(v.shape)
+            rows = slice(0, v.shape[0])
+        elif s.transpose:
             dw = dwv[0, :, : s.c_in].reshape(s.k, s.c_out, s.c_in).permute(2, 1, 0)      # [c_in][c_out][k]
             rows = slice(0, s.c_in)
         else:
@@ -160,8 +165,9 @@ def weight_prep_bwd(arena):
         if s.g is None:
             arena.dparam_views[pid[id(s.v)]][rows] = dw
         else:
-            n = torch.linalg.vector_norm(vr, 2, dim=(1, 2), keepdim=True)
-            dot = (dw * vr).sum((1, 2), keepdim=True)
+            dims = tuple(range(1, vr.dim()))
+            n = torch.linalg.vector_norm(vr, 2, dim=dims, keepdim=True)
+            dot = (dw * vr).sum(dims, keepdim=True)
             gg = s.g.detach().float()[rows]
             arena.dparam_views[pid[id(s.v)]][rows] = (gg / n) * (dw - vr * dot / (n * n))
             arena.dparam_views[pid[id(s.g)]][rows] = dot / n

@@ -35,3 +35,21 @@ def test_discriminator_p(emulated, period):
     assert rel_err(xp.grad, xo.grad) < 2e-5
     for k, p in d.named_parameters():
         assert rel_err(p.grad, sd["d." + k].grad) < 5e-5, k
+
+
+def test_mpd_library_path_through_arena(emulated):
+    """MultiPeriodDiscriminator on the library-convolution path with the weight-norm of all 37 layers coming from
+    the arena (torch-layout operands): outputs and parameter gradients equal the oracle."""
+    pkg = emulated
+    torch.manual_seed(0)
+    d = pkg.MultiPeriodDiscriminator(False)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in d.state_dict().items()}
+    y, y_hat = torch.rand(1, 1, 600) * 2 - 1, torch.rand(1, 1, 600) * 2 - 1
+    rs, gs, fr, fg = d(y, y_hat)
+    ro, go, fro, fgo = O.mpd(sd, y, y_hat)
+    for a, b in zip(rs + gs, ro + go):
+        assert rel_err(a, b) < 1e-5
+    (sum(g.pow(2).mean() for g in gs) + sum(f.abs().mean() for fm in fg for f in fm)).backward()
+    (sum(g.pow(2).mean() for g in go) + sum(f.abs().mean() for fm in fgo for f in fm)).backward()
+    for k, p in d.named_parameters():
+        assert rel_err(p.grad, sd[k].grad) < 5e-5, k
