@@ -34,7 +34,8 @@ struct WgradArgs {
   float in_slope;
   int flags;
   int ldx, lddy, stride;
-  float* partial_db;      // [S][Cout] per-split bias-gradient sums, or null
+  float* partial_db;      // per-split bias-gradient sums (slab pitch `slab`), or null
+  size_t slab;            // floats per split in `partial` (dw slab, optionally followed by the db slab)
 };
 
 __device__ __forceinline__ float to_f(float v) { return v; }
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
     red[tid] = db_acc;
     __syncthreads();
     if (tid < 64 && co0 + tid < a.Cout)
-      a.partial_db[(size_t)blockIdx.x * a.Cout + co0 + tid] = red[tid] + red[tid + 64] + red[tid + 128] + red[tid + 192];
+      a.partial_db[(size_t)blockIdx.x * a.slab + co0 + tid] = red[tid] + red[tid + 64] + red[tid + 128] + red[tid + 192];
     __syncthreads();
   }
   if constexpr (SMALL) {                                  // sum the four waves' accumulators (fixed order) into wave 0
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
     }
   }
   // slab of this split: partial[split][tap][co][ci]
-  float* P = a.partial + (size_t)blockIdx.x * a.K * a.Cout * a.Cin;
+  float* P = a.partial + (size_t)blockIdx.x * a.slab;
   const int ci = ci0 + wj * 32 + r;
   if (ci < a.Cin && (!SMALL || wave == 0)) {
 #pragma unroll
@@ -275,16 +276,19 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
   }
 }
 
-// dw[i] (+)= sum_s partial[s][i], fixed summation order.  One thread per 4 consecutive elements.
-__global__ void reduce_slabs(const float* __restrict__ partial, float* __restrict__ dw, size_t n4, size_t n, int S, int accumulate) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n4) return;
-  float4 acc = accumulate ? reinterpret_cast<const float4*>(dw)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+// out[i] (+)= sum_s partial[s * slab + i] in a fixed order; elements i < n go to dw, the following nb to db.
+// One thread per 4 consecutive elements (n and nb are multiples of 4).
+__global__ void reduce_slabs(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db, size_t n, size_t nb,
+                             size_t slab, int S, int accumulate) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n + nb) return;
+  float* dst = (i < n) ? dw + i : db + (i - n);
+  float4 acc = accumulate ? *reinterpret_cast<const float4*>(dst) : make_float4(0.f, 0.f, 0.f, 0.f);
   for (int k = 0; k < S; ++k) {
-    const float4 v = reinterpret_cast<const float4*>(partial + (size_t)k * n)[i];
+    const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)k * slab + i);
     acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
   }
-  reinterpret_cast<float4*>(dw)[i] = acc;
+  *reinterpret_cast<float4*>(dst) = acc;
 }
 
 int taps_per_group(int k) { return k <= 4 ? k : (k <= 8 ? (k + 1) / 2 : 4); }
@@ -355,10 +359,13 @@ extern "C" int vits_conv1d_cl_wgrad(const vits_wgrad_desc* desc, void* stream) {
   if (d.ldx <= 0) d.ldx = d.c_in;
   if (d.lddy <= 0) d.lddy = d.c_out;
   const int S = pick_splits(d.b, t_out, d.c_in, d.c_out, d.k);
+  const size_t n = (size_t)d.k * d.c_out * d.c_in, nb = d.dbias ? (size_t)d.c_out : 0;   // multiples of 4
+  const bool accumulate = (d.flags & VITS_CONV_ACCUM) != 0;
+  const bool direct = (S == 1) && !accumulate;           // a single split writes dw / db itself: no second launch
   float* ws = static_cast<float*>(d.workspace);
-  WgradArgs a{d.x, d.dy, ws, d.lengths, d.b, d.t, t_out, d.c_in, d.c_out, d.k, d.dil, d.pad,
+  WgradArgs a{d.x, d.dy, direct ? d.dw : ws, d.lengths, d.b, d.t, t_out, d.c_in, d.c_out, d.k, d.dil, d.pad,
               S, vits::ceil_div(t_out, TK), d.in_slope, d.flags, d.ldx, d.lddy, d.stride,
-              d.dbias ? ws + (size_t)S * d.k * d.c_out * d.c_in : nullptr};
+              d.dbias ? (direct ? d.dbias : ws + n) : nullptr, direct ? 0 : n + nb};
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc;
   if (d.dtype == VITS_DT_BF16) {
@@ -371,13 +378,8 @@ extern "C" int vits_conv1d_cl_wgrad(const vits_wgrad_desc* desc, void* stream) {
     return VITS_E_UNSUPPORTED;
   }
   if (rc != VITS_OK) return rc;
-  const size_t n = (size_t)d.k * d.c_out * d.c_in;          // multiple of 16 (c_in % 4 == 0 and c_out % 4 == 0)
-  hipLaunchKernelGGL(reduce_slabs, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, a.partial, d.dw, n / 4, n, a.S,
-                     (d.flags & VITS_CONV_ACCUM) ? 1 : 0);
-  if (d.dbias) {                                           // c_out % 4 == 0
-    const size_t nb = (size_t)d.c_out;
-    hipLaunchKernelGGL(reduce_slabs, dim3((unsigned)((nb / 4 + 255) / 256)), dim3(256), 0, s, a.partial_db, d.dbias, nb / 4, nb, a.S,
-                       (d.flags & VITS_CONV_ACCUM) ? 1 : 0);
-  }
+  if (direct) return VITS_OK;
+  hipLaunchKernelGGL(reduce_slabs, dim3((unsigned)(((n + nb) / 4 + 255) / 256)), dim3(256), 0, s, a.partial, d.dw, d.dbias, n, nb,
+                     a.slab, a.S, accumulate ? 1 : 0);
   return vits::check_launch("vits_conv1d_cl_wgrad/reduce");
 }
