@@ -21,6 +21,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # before the HIP runtime initialises; see the package __init__
+
 import torch
 import torch.distributed as dist
 
@@ -108,6 +110,7 @@ def main():
     use_graph = (world == 1) and not args.eager
     if use_graph:
         tuner.capture(batch, warmup=3)
+        tuner.verify_replay()                            # same state -> same result, and agrees with the eager step
         step = tuner.replay
     else:
         step = lambda: tuner.step(batch)

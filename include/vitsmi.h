@@ -106,6 +106,8 @@ int vits_mas_f32(const float* neg_cent, void* path, int path_dtype,
                                    y[.., c] = v * sigmoid(b) * (1 - tanh(a)^2),  y[.., c + gate_h] = v * tanh(a) * sigmoid(b) * (1 - sigmoid(b));
                                    y and mg_src have 2*gate_h columns */
 
+#define VITS_CONV_FLAT      256 /* force the flat-row kernel (rows = (item, time) pairs; chosen automatically for strided,
+                                   divided and short-sequence launches) */
 #define VITS_CONV_OUT_LRELU 128 /* y = leaky_relu(., out_slope) applied after residual/scale (discriminator feature maps) */
 
 /* All sizes in elements.  Zero in ldx / ldy / ldy2 / stride means "dense" / 1. */
@@ -119,7 +121,10 @@ typedef struct vits_conv_desc {
   int32_t ldy2;             /* row pitch of y2                                                            */
   int32_t gate_h;           /* H of the gate flags                                                        */
   int32_t ldw;              /* row pitch of w (>= c_in; 0 = dense): w rows may be channel slices            */
-  int32_t reserved0;
+  int32_t in_div;           /* > 1: data gradient of a stride-`in_div` convolution (stride must be 1): the input time of
+                               tap j for output t is (t + j*dil - pad) / in_div when divisible, else the tap is zero      */
+  int32_t t_out_override;   /* output length when in_div > 1 (= the forward convolution's input length)                */
+  int32_t reserved1;
   int64_t w_batch_stride;   /* elements between the operands of consecutive batch items; 0 = one shared w:
                                with k = 1 this makes the call a batched product Y[b] = X[b] . W[b]^T (attention) */
   float in_slope, mg_slope, out_scale, out_slope;

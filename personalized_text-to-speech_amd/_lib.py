@@ -10,7 +10,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvitsmi.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_int = ctypes.c_int
 c_void_p = ctypes.c_void_p
@@ -44,7 +44,7 @@ SIGNATURES = {
 class ConvDesc(ctypes.Structure):
     """vits_conv_desc of include/vitsmi.h"""
     _fields_ = [(n, ctypes.c_int32) for n in ("dtype", "b", "t", "c_in", "c_out", "k", "dil", "pad", "stride", "flags",
-                                              "ldx", "ldy", "ldy2", "gate_h", "ldw", "reserved0")] + \
+                                              "ldx", "ldy", "ldy2", "gate_h", "ldw", "in_div", "t_out_override", "reserved1")] + \
                [("w_batch_stride", ctypes.c_int64)] + \
                [(n, c_float) for n in ("in_slope", "mg_slope", "out_scale", "out_slope")] + \
                [(n, c_void_p) for n in ("x", "w", "bias", "bias_b", "res", "mg_src", "y", "y2", "lengths")]

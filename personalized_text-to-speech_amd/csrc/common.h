@@ -19,4 +19,7 @@ inline int check_launch(const char* where) {
 
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// csrc/conv1d_flat.hip: flat-row (gathering) variant of the channels-last convolution
+int conv1d_flat_dispatch(const vits_conv_desc& d, int t_out, hipStream_t s);
+
 }  // namespace vits

@@ -26,6 +26,7 @@
 // Fused epilogue (flags): + bias[co] + bias_b[b][co] (speaker conditioning) + residual, * scale,
 // * leaky-relu'(src) (chain rule of a fused input activation, for the data-gradient call),
 // residual after the multiplier (skip connection of a data gradient), row mask, tanh, accumulate.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -310,9 +311,13 @@ int launch_conv(const vits_conv_desc& d, int t_out, hipStream_t s) {
   const size_t lds = (size_t)xrows * PITCH + (size_t)G * TN * PITCH;
   if (lds > (size_t)vits::kLdsBytesMax) return VITS_E_UNSUPPORTED;
   auto kern = conv1d_cl_kernel<T, NT, WM>;
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  // once per kernel instance, to the hardware maximum: a per-launch value would be whatever the LAST call set by
+  // the time a captured graph replays its nodes
+  static bool lds_attr_set = false;
+  if (!lds_attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, vits::kLdsBytesMax);
     if (e != hipSuccess) return vits::note_hip_error(e, "vits_conv1d_cl/attr");
+    lds_attr_set = true;
   }
   const bool gate = (d.flags & VITS_CONV_GATE) != 0;
   const int cols = gate ? d.gate_h : d.c_out;
@@ -348,9 +353,16 @@ extern "C" int vits_conv1d_cl(const vits_conv_desc* desc, void* stream) {
   if (!d.x || !d.w || !d.y || d.b <= 0 || d.t <= 0 || d.c_in <= 0 || d.c_out <= 0 || d.k <= 0 || d.dil <= 0 || d.pad < 0)
     return VITS_E_BADARG;
   if (d.stride <= 0) d.stride = 1;
-  const int span = d.t + 2 * d.pad - d.dil * (d.k - 1) - 1;
-  if (span < 0) return VITS_E_BADARG;
-  const int t_out = span / d.stride + 1;
+  const int in_div = d.in_div > 1 ? d.in_div : 1;
+  int t_out;
+  if (in_div > 1) {                         // data gradient of a strided convolution: the caller states the output length
+    if (d.stride != 1 || d.t_out_override <= 0) return VITS_E_BADARG;
+    t_out = d.t_out_override;
+  } else {
+    const int span = d.t + 2 * d.pad - d.dil * (d.k - 1) - 1;
+    if (span < 0) return VITS_E_BADARG;
+    t_out = span / d.stride + 1;
+  }
   if (((d.flags & (VITS_CONV_MASK_IN | VITS_CONV_MASK_OUT)) != 0) && !d.lengths) return VITS_E_BADARG;
   const bool gate = (d.flags & VITS_CONV_GATE) != 0, gate_bwd = (d.flags & VITS_CONV_GATE_BWD) != 0;
   if (gate && (d.gate_h <= 0 || d.c_out != 2 * d.gate_h)) return VITS_E_BADARG;
@@ -361,13 +373,19 @@ extern "C" int vits_conv1d_cl(const vits_conv_desc* desc, void* stream) {
   if (d.ldy <= 0) d.ldy = gate ? d.gate_h : (gate_bwd ? 2 * d.gate_h : d.c_out);
   if (d.ldy2 <= 0) d.ldy2 = d.c_out;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (d.dtype == VITS_DT_BF16) {
-    if (d.c_in % 8 != 0 || d.ldx % 8 != 0 || d.ldw % 8 != 0 || d.w_batch_stride % 8 != 0) return VITS_E_UNSUPPORTED;
-    return dispatch_tile<__bf16>(d, t_out, s);
+  const int vec = d.dtype == VITS_DT_BF16 ? 8 : (d.dtype == VITS_DT_F32 ? 4 : 0);
+  if (vec == 0) return VITS_E_UNSUPPORTED;
+  if (d.c_in % vec != 0 || d.ldx % vec != 0 || d.ldw % vec != 0 || d.w_batch_stride % vec != 0) return VITS_E_UNSUPPORTED;
+  // flat-row kernel: strided / divided launches, and short sequences spread over many items (most of a per-item
+  // time tile would be empty).  It has no gate epilogues and no per-item operands.
+  const bool flat_ok = !gate && !gate_bwd && d.w_batch_stride == 0 && d.y2 == nullptr;
+  const bool must_flat = in_div > 1 || (d.flags & VITS_CONV_FLAT) != 0;
+  if (must_flat && !flat_ok) return VITS_E_UNSUPPORTED;
+  static const bool auto_flat = !(getenv("VITS_FLAT_AUTO") && getenv("VITS_FLAT_AUTO")[0] == '0');
+  if (must_flat || (flat_ok && (d.stride > 1 || (auto_flat && t_out <= 80 && d.b >= 8)))) {
+    const int rc = vits::conv1d_flat_dispatch(d, t_out, s);
+    if (rc != VITS_E_UNSUPPORTED || must_flat) return rc;
   }
-  if (d.dtype == VITS_DT_F32) {
-    if (d.c_in % 4 != 0 || d.ldx % 4 != 0 || d.ldw % 4 != 0 || d.w_batch_stride % 4 != 0) return VITS_E_UNSUPPORTED;
-    return dispatch_tile<float>(d, t_out, s);
-  }
-  return VITS_E_UNSUPPORTED;
+  if (d.dtype == VITS_DT_BF16) return dispatch_tile<__bf16>(d, t_out, s);
+  return dispatch_tile<float>(d, t_out, s);
 }

@@ -15,6 +15,7 @@
 // accumulator per tap); the next chunk's tiles are prefetched into registers during the MFMAs.  The (b, t) reduction is split over blockIdx.x; every split writes its own
 // fp32 slab and a second kernel sums the slabs in a fixed order (bitwise reproducible — no float
 // atomics, cdna_hip_programming.md Guideline 12).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -63,13 +64,15 @@ template <> struct Pitch<float> { static constexpr int value = CT * 4 + 16; };
 
 constexpr int DV_MAX = 8;      // 16-byte vectors of the dY tile per thread (TK*VPR <= 256*DV_MAX)
 constexpr int XV_MAX = 10;     // ... of the X tile (xrows*VPR <= 256*XV_MAX, else staged synchronously)
+constexpr int XV_FLAT = 12;    // ... of the gathered per-tap X tiles of the flat-row variant (3 taps x 128 rows x 8 vectors)
+constexpr int KT_FLAT = 3;
 
 // One workgroup = one 64(co) x 64(ci) tile x one GROUP of at most KT taps x one split of the (b,t) reduction.
 // Splitting the taps over workgroups multiplies the parallelism of large-k layers without any extra slab
 // traffic (the tiles of x and dy are re-read from L2), and keeps the accumulators at KT*16 registers.
 // SMALL = true: c_out <= 32 and c_in <= 32 (last decoder stage): the four waves share the single 32x32 block
 // and split each chunk's 128 rows among themselves; their accumulators are summed through LDS at the end.
-template <typename T, int KT, bool SMALL>
+template <typename T, int KT, bool SMALL, bool FLAT>
 __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int V = 16 / sizeof(T);
@@ -82,11 +85,14 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
   const int co0 = blockIdx.y * CT, ci0 = (blockIdx.z % n_ci_tiles) * CT;
   const int tap0 = (blockIdx.z / n_ci_tiles) * KT;
   const int ntap = (a.K - tap0 < KT) ? (a.K - tap0) : KT;
-  const int xrows = (TK - 1) * a.stride + (ntap - 1) * a.dil + 1;
+  // FLAT: chunks are TK consecutive rows of the joint (item, time) index and every tap has its own gathered
+  // [TK][CT] tile (period-discriminator shapes: many short items, strided) — see csrc/conv1d_flat.hip.
+  const int xrows = FLAT ? ntap * TK : (TK - 1) * a.stride + (ntap - 1) * a.dil + 1;
+  constexpr int XV = FLAT ? XV_FLAT : XV_MAX;
   unsigned char* ldsD = smem;                               // [TK][CT] of dY
   unsigned char* ldsX = smem + (size_t)TK * PITCH;          // [xrows][CT] of act(X), first row = tap0's
   const int dvec = TK * VPR, xvec = xrows * VPR;
-  const bool x_in_regs = xvec <= kThreads * XV_MAX;
+  const bool x_in_regs = xvec <= kThreads * XV;
 
   f32x16 acc[KT];
 #pragma unroll
@@ -94,8 +100,9 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
 
-  u32x4 dr[DV_MAX], xr[XV_MAX];
+  u32x4 dr[DV_MAX], xr[XV];
   auto chunk_info = [&](int ch, int& b, int& t0, int& t_out_hi, int& t_in_hi) {
+    if constexpr (FLAT) { b = 0; t0 = ch * TK; t_out_hi = a.B * a.Tout; t_in_hi = a.T; return; }
     b = ch / a.chunks_per_item;
     t0 = (ch % a.chunks_per_item) * TK;
     const int len = a.lengths ? a.lengths[b] : a.T;
@@ -104,8 +111,17 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
   };
   auto load_x_vec = [&](const T* X, int idx, int t0, int t_in_hi) -> u32x4 {
     const int row = idx / VPR, vc = idx % VPR;
-    const int t = t0 * a.stride - a.pad + tap0 * a.dil + row, ci = ci0 + vc * V;
+    int t = t0 * a.stride - a.pad + tap0 * a.dil + row;
+    const int ci = ci0 + vc * V;
     u32x4 v = {0u, 0u, 0u, 0u};
+    if constexpr (FLAT) {                    // t0 = first flat row of the chunk; X = base of the whole tensor
+      const int kk = row / TK, m = t0 + (row - kk * TK);
+      if (m >= a.B * a.Tout) return v;
+      const int b = m / a.Tout;
+      t = (m - b * a.Tout) * a.stride + (tap0 + kk) * a.dil - a.pad;
+      if (a.flags & VITS_CONV_MASK_IN) { const int len = a.lengths[b]; t_in_hi = len < a.T ? len : a.T; }
+      X += (size_t)b * a.T * a.ldx;
+    }
     if (t >= 0 && t < t_in_hi && ci < a.Cin) {
       v = *reinterpret_cast<const u32x4*>(X + (size_t)t * a.ldx + ci);
       if (a.in_slope != 1.0f) v = lrelu_vec<T>(v, a.in_slope);
@@ -124,13 +140,17 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
       if (idx < dvec) {
         const int row = idx / VPR, vc = idx % VPR;
         const int t = t0 + row, co = co0 + vc * V;
-        if (t < t_out_hi && co < a.Cout) v = *reinterpret_cast<const u32x4*>(DY + (size_t)t * a.lddy + co);
+        bool ok = t < t_out_hi && co < a.Cout;
+        if constexpr (FLAT) {
+          if (ok && (a.flags & VITS_CONV_MASK_OUT)) { const int bb = t / a.Tout; ok = (t - bb * a.Tout) < a.lengths[bb]; }
+        }
+        if (ok) v = *reinterpret_cast<const u32x4*>(DY + (size_t)t * a.lddy + co);
       }
       dr[i] = v;
     }
     if (x_in_regs) {
 #pragma unroll
-      for (int i = 0; i < XV_MAX; ++i) {
+      for (int i = 0; i < XV; ++i) {
         const int idx = tid + i * kThreads;
         xr[i] = (idx < xvec) ? load_x_vec(X, idx, t0, t_in_hi) : u32x4{0u, 0u, 0u, 0u};
       }
@@ -144,7 +164,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
     }
     if (x_in_regs) {
 #pragma unroll
-      for (int i = 0; i < XV_MAX; ++i) {
+      for (int i = 0; i < XV; ++i) {
         const int idx = tid + i * kThreads;
         if (idx < xvec) *reinterpret_cast<u32x4*>(ldsX + (idx / VPR) * PITCH + (idx % VPR) * 16) = xr[i];
       }
@@ -161,7 +181,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
   const bool do_db = (a.partial_db != nullptr) && (blockIdx.z == 0);
   float db_acc = 0.f;
 
-  const int n_chunks = a.B * a.chunks_per_item;
+  const int n_chunks = FLAT ? (a.B * a.Tout + TK - 1) / TK : a.B * a.chunks_per_item;
   int ch = blockIdx.x;
   if (ch < n_chunks) { load_chunk(ch); store_chunk(ch); }
   __syncthreads();
@@ -201,7 +221,8 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
             for (int rd = 0; rd < 2; ++rd) {
               auto pb = reinterpret_cast<__attribute__((address_space(3))) s16x4*>(
-                  (__attribute__((address_space(3))) unsigned char*)ldsX + ((16 * s + rowk + 4 * rd) * a.stride + k * a.dil) * PITCH + colB);
+                  (__attribute__((address_space(3))) unsigned char*)ldsX +
+                  (FLAT ? (k * TK + 16 * s + rowk + 4 * rd) : ((16 * s + rowk + 4 * rd) * a.stride + k * a.dil)) * PITCH + colB);
               fb.half[rd] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(pb);
             }
             acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, fb.v, acc[k], 0, 0, 0);
@@ -219,7 +240,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
           if (k < ntap) {
-            const float bv = xB[((2 * s + h) * a.stride + k * a.dil) * PF];
+            const float bv = xB[(FLAT ? (k * TK + 2 * s + h) : ((2 * s + h) * a.stride + k * a.dil)) * PF];
             acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[k], 0, 0, 0);
           }
         }
@@ -295,10 +316,10 @@ int taps_per_group(int k) { return k <= 4 ? k : (k <= 8 ? (k + 1) / 2 : 4); }
 
 // Number of (b,t)-reduction splits: enough workgroups to fill the chip (together with the tile and tap-group
 // dimensions), but never more slab traffic than ~2x the reads of x and dy (each split writes and re-reads one dW).
-int pick_splits(int b, int t_out, int c_in, int c_out, int k) {
-  const int kt = taps_per_group(k);
+int pick_splits(int b, int t_out, int c_in, int c_out, int k, bool flat = false) {
+  const int kt = flat ? (k < KT_FLAT ? k : KT_FLAT) : taps_per_group(k);
   const int groups = vits::ceil_div(c_out, CT) * vits::ceil_div(c_in, CT) * vits::ceil_div(k, kt);
-  const int chunks = b * vits::ceil_div(t_out, TK);
+  const int chunks = flat ? vits::ceil_div(b * t_out, TK) : b * vits::ceil_div(t_out, TK);
   int s = vits::ceil_div(768, groups);
   const double io_elems = (double)b * t_out * (c_in + c_out);          // read once, 2 B (bf16) each
   const double dw_elems = (double)k * c_out * c_in;                    // each split writes + re-reads it in fp32: 8 B each
@@ -311,16 +332,20 @@ int pick_splits(int b, int t_out, int c_in, int c_out, int k) {
   return s;
 }
 
-template <typename T, int KT, bool SMALL>
+template <typename T, int KT, bool SMALL, bool FLAT = false>
 int launch(const WgradArgs& a, hipStream_t s) {
   constexpr int PITCH = Pitch<T>::value;
-  size_t lds = (size_t)(TK + (TK - 1) * a.stride + (KT - 1) * a.dil + 1) * PITCH;
+  size_t lds = FLAT ? (size_t)(1 + KT) * TK * PITCH : (size_t)(TK + (TK - 1) * a.stride + (KT - 1) * a.dil + 1) * PITCH;
   if (SMALL && lds < (size_t)3 * KT * 16 * 64 * 4) lds = (size_t)3 * KT * 16 * 64 * 4;
   if (lds > (size_t)vits::kLdsBytesMax) return VITS_E_UNSUPPORTED;
-  auto kern = wgrad_kernel<T, KT, SMALL>;
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  auto kern = wgrad_kernel<T, KT, SMALL, FLAT>;
+  // once per kernel instance, to the hardware maximum: a per-launch value would be whatever the LAST call set by
+  // the time a captured graph replays its nodes
+  static bool lds_attr_set = false;
+  if (!lds_attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, vits::kLdsBytesMax);
     if (e != hipSuccess) return vits::note_hip_error(e, "vits_conv1d_cl_wgrad/attr");
+    lds_attr_set = true;
   }
   dim3 grid(a.S, vits::ceil_div(a.Cout, CT), vits::ceil_div(a.Cin, CT) * vits::ceil_div(a.K, KT));
   hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, s, a);
@@ -328,7 +353,14 @@ int launch(const WgradArgs& a, hipStream_t s) {
 }
 
 template <typename T>
-int dispatch_k(const WgradArgs& a, hipStream_t s) {
+int dispatch_k(const WgradArgs& a, hipStream_t s, bool flat) {
+  if (flat) {
+    switch (a.K < KT_FLAT ? a.K : KT_FLAT) {
+      case 1: return launch<T, 1, false, true>(a, s);
+      case 2: return launch<T, 2, false, true>(a, s);
+      default: return launch<T, 3, false, true>(a, s);
+    }
+  }
   const bool small = a.Cout <= 32 && a.Cin <= 32;
   switch (taps_per_group(a.K)) {
     case 1: return small ? launch<T, 1, true>(a, s) : launch<T, 1, false>(a, s);
@@ -358,7 +390,11 @@ extern "C" int vits_conv1d_cl_wgrad(const vits_wgrad_desc* desc, void* stream) {
   if (d.workspace_bytes < vits_conv1d_cl_wgrad_workspace(d.b, t_out, d.c_in, d.c_out, d.k)) return VITS_E_BADARG;
   if (d.ldx <= 0) d.ldx = d.c_in;
   if (d.lddy <= 0) d.lddy = d.c_out;
-  const int S = pick_splits(d.b, t_out, d.c_in, d.c_out, d.k);
+  // flat-row variant: strided layers and many short items (same rule as vits_conv1d_cl); never more splits than the
+  // per-item variant, so the workspace bound above holds for both
+  static const bool auto_flat = !(getenv("VITS_FLAT_AUTO") && getenv("VITS_FLAT_AUTO")[0] == '0');
+  const bool flat = d.stride > 1 || (d.flags & VITS_CONV_FLAT) != 0 || (auto_flat && t_out <= 80 && d.b >= 8);
+  const int S = pick_splits(d.b, t_out, d.c_in, d.c_out, d.k, flat);
   const size_t n = (size_t)d.k * d.c_out * d.c_in, nb = d.dbias ? (size_t)d.c_out : 0;   // multiples of 4
   const bool accumulate = (d.flags & VITS_CONV_ACCUM) != 0;
   const bool direct = (S == 1) && !accumulate;           // a single split writes dw / db itself: no second launch
@@ -370,10 +406,10 @@ extern "C" int vits_conv1d_cl_wgrad(const vits_wgrad_desc* desc, void* stream) {
   int rc;
   if (d.dtype == VITS_DT_BF16) {
     if (d.c_in % 8 != 0 || d.c_out % 8 != 0 || d.ldx % 8 != 0 || d.lddy % 8 != 0) return VITS_E_UNSUPPORTED;
-    rc = dispatch_k<__bf16>(a, s);
+    rc = dispatch_k<__bf16>(a, s, flat);
   } else if (d.dtype == VITS_DT_F32) {
     if (d.c_in % 4 != 0 || d.c_out % 4 != 0 || d.ldx % 4 != 0 || d.lddy % 4 != 0) return VITS_E_UNSUPPORTED;
-    rc = dispatch_k<float>(a, s);
+    rc = dispatch_k<float>(a, s, flat);
   } else {
     return VITS_E_UNSUPPORTED;
   }

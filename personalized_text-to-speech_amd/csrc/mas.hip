@@ -205,10 +205,12 @@ int launch(const float* neg_cent, void* path, uint32_t one_bits, const int32_t* 
   const size_t lds = (fixed + (size_t)n_slots * R * rs) * 4;
   if (lds > (size_t)vits::kLdsBytesMax) return VITS_E_UNSUPPORTED;
   auto kern = mas_kernel<E>;
-  if (lds > 64 * 1024) {
+  static bool lds_attr_set = false;                  // once per instance, hardware maximum (graph-replay safe)
+  if (!lds_attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, vits::kLdsBytesMax);
     if (e != hipSuccess) return vits::note_hip_error(e, "vits_mas_f32/attr");
+    lds_attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(b), dim3(kThreads), lds, stream, neg_cent, static_cast<uint32_t*>(path),
                      t_ys, t_xs, t_t, t_s, n_slots, one_bits, status);

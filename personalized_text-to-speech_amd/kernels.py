@@ -175,6 +175,7 @@ def stft_magnitude(y, n_fft, hop, win, window):
 # contiguous, weights are tap-major [k, c_out, c_in] in the activation dtype.
 # ================================================================================================
 CONV_MASK_IN, CONV_MASK_OUT, CONV_TANH, CONV_ACCUM, CONV_RES_AFTER, CONV_GATE, CONV_GATE_BWD, CONV_OUT_LRELU = 1, 2, 4, 8, 16, 32, 64, 128
+CONV_FLAT = 256
 _DT = {torch.float32: 0, torch.bfloat16: 2}
 
 
@@ -187,7 +188,7 @@ def _rows(t, name):
 
 
 def conv1d_cl_raw(x, w, bias=None, bias_b=None, res=None, mg_src=None, out=None, lengths=None, dil=1, pad=0, stride=1,
-                  in_slope=1.0, mg_slope=1.0, out_scale=1.0, flags=0, gate_h=0, out2=None, out_slope=None):
+                  in_slope=1.0, mg_slope=1.0, out_scale=1.0, flags=0, gate_h=0, out2=None, out_slope=None, in_div=1, t_out=None):
     """Launch vits_conv1d_cl.  x [b,t,c_in], w [k,c_out,c_in] (tap-major) in the same dtype; see
     include/vitsmi.h for the fused prologue/epilogue.  Returns y (allocated unless `out` is given)."""
     _lib.require_cuda(x, w)
@@ -202,7 +203,10 @@ def conv1d_cl_raw(x, w, bias=None, bias_b=None, res=None, mg_src=None, out=None,
         assert w.dim() == 3 and w.is_contiguous()
         k, c_out, c_in_w = w.shape
     assert c_in_w == c_in, (tuple(x.shape), tuple(w.shape))
-    t_out = (t + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    if in_div > 1:                         # data gradient of a stride-`in_div` convolution: the caller states the length
+        assert stride == 1 and t_out is not None
+    else:
+        t_out = (t + 2 * pad - dil * (k - 1) - 1) // stride + 1
     y_cols = gate_h if (flags & CONV_GATE) else (2 * gate_h if (flags & CONV_GATE_BWD) else c_out)
     if out is None:
         assert not (flags & CONV_ACCUM)
@@ -219,7 +223,7 @@ def conv1d_cl_raw(x, w, bias=None, bias_b=None, res=None, mg_src=None, out=None,
         flags |= CONV_OUT_LRELU
     d = _lib.ConvDesc(dtype=_DT[x.dtype], b=b, t=t, c_in=c_in, c_out=c_out, k=k, dil=dil, pad=pad, stride=stride, flags=int(flags),
                       ldx=_rows(x, "x"), ldy=ldy, ldy2=0 if out2 is None else _rows(out2, "out2"), gate_h=gate_h,
-                      ldw=ldw, reserved0=0, w_batch_stride=wbs,
+                      ldw=ldw, in_div=in_div, t_out_override=(t_out if in_div > 1 else 0), reserved1=0, w_batch_stride=wbs,
                       in_slope=float(in_slope), mg_slope=float(mg_slope), out_scale=float(out_scale), out_slope=float(out_slope or 0.0),
                       x=x.data_ptr(), w=w.data_ptr(), bias=p(bias), bias_b=p(bias_b), res=p(res), mg_src=p(mg_src),
                       y=out.data_ptr(), y2=p(out2), lengths=p(lengths))
@@ -230,7 +234,7 @@ def conv1d_cl_raw(x, w, bias=None, bias_b=None, res=None, mg_src=None, out=None,
         es = x.element_size()
         _lib.timer.stop("vits_conv1d_cl", e0, (2.0 * b * t_out * c_out * c_in * k,
                                                 es * (b * t * c_in + b * t_out * out.size(2) + k * c_out * c_in + (0 if res is None else res.numel()))),
-                        shape=f"b{b} t{t} ci{c_in} co{c_out} k{k} d{dil} s{stride} f{flags} {str(x.dtype)[6:]}")
+                        shape=f"b{b} t{t} ci{c_in} co{c_out} k{k} d{dil} s{stride}/{in_div} f{flags} {str(x.dtype)[6:]}")
     _lib.check(rc, "vits_conv1d_cl")
     return out
 

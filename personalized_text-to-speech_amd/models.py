@@ -4,6 +4,8 @@ tuples, so checkpoints and callers are interchangeable.  File:line citations poi
 """
 import math
 
+import os
+
 import torch
 from torch import nn
 from torch.nn import functional as F
@@ -307,11 +309,10 @@ class DiscriminatorP(nn.Module):
             _WNConv2dK1(1024, 1024, kernel_size, 1, p)])
         self.conv_post = _WNConv2dK1(1024, 1, 3, 1, 1)
 
-    # The HIP path is correct (tests/test_disc_logic_cpu.py, test_model_gpu.py) but today slower than MIOpen's
-    # implicit-GEMM kernels on these shapes (deep layers have 10-51 rows per folded batch element, so the
-    # per-element time tiling of vits_conv1d_cl wastes most of each tile, and the strided data gradient uses
-    # zero insertion): 90 vs 80 ms/step.  It is switched on once the flat (b,t)-row tiling lands.
-    use_hip = False
+    # HIP path: the flat-row kernels (csrc/conv1d_flat.hip, FLAT weight gradient) tile the joint (item, time) index,
+    # which is what these shapes need (deep layers have 10-51 rows per folded batch element).  VITS_DISC_P=library
+    # selects the MIOpen convolutions instead (A/B measurements only).
+    use_hip = os.environ.get("VITS_DISC_P", "hip") != "library"
 
     def forward(self, x):
         return self.forward_hip(x) if DiscriminatorP.use_hip else self.forward_rocm(x)

@@ -131,6 +131,50 @@ class FineTuner:
         _lib.timer.enabled = timer_was
         return self._static_out
 
+    def _state_tensors(self):
+        ts = [p for p in self.net_g.parameters()] + [p for p in self.net_d.parameters()]
+        for opt in (self.optim_g, self.optim_d):
+            for st in opt.state.values():
+                ts += [v for v in st.values() if torch.is_tensor(v)]
+        return ts
+
+    def verify_replay(self, rtol=1e-3):
+        """Replays the captured step twice from the SAME parameters, optimizer state and generator state and checks
+        that both replays report the same losses and leave the same parameters; then runs the step eagerly from that
+        state and checks the replayed losses against it (loosely: eager and captured noise draws differ).  State is
+        restored afterwards.  Guards the measurement against graph-replay hazards (stale memset nodes, buffers a
+        replay depends on from the previous one)."""
+        assert self._graph is not None
+        ts = self._state_tensors()
+        snap = [t.detach().clone() for t in ts]
+        rng = torch.cuda.get_rng_state(self.device)
+
+        def restore():
+            with torch.no_grad():
+                for t, s in zip(ts, snap):
+                    t.copy_(s)
+            torch.cuda.set_rng_state(rng, self.device)
+
+        def run(fn):
+            out = fn()
+            torch.cuda.synchronize()
+            losses = {k: float(v) for k, v in out.items()}
+            probe = float(sum(p.detach().float().abs().sum() for p in list(self.net_g.parameters())[:8]))
+            restore()
+            return losses, probe
+
+        a, pa = run(self.replay)
+        b, pb = run(self.replay)
+        e, _ = run(lambda: self.step(self._static_batch))
+        close = lambda u, v, tol: u == v or abs(u - v) <= tol * max(abs(u), abs(v), 1e-6)
+        bad = [k for k in a if not (close(a[k], b[k], rtol))]
+        if bad or not close(pa, pb, rtol):
+            raise RuntimeError(f"graph replay is not reproducible: {[(k, a[k], b[k]) for k in bad]} probe {pa} vs {pb}")
+        off = [k for k in ("loss_disc", "loss_mel", "loss_fm", "loss_gen") if not close(a[k], e[k], 0.25)]
+        if off:
+            raise RuntimeError(f"graph replay disagrees with the eager step: {[(k, a[k], e[k]) for k in off]}")
+        return a
+
     def load_batch(self, batch):
         for dst, src in zip(self._static_batch, batch):
             dst.copy_(src, non_blocking=True)

@@ -82,12 +82,10 @@ class ConvCLFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[1]:
             xs = xd if xd.is_contiguous() else xd.contiguous()
-            dyu = dy
-            if stride != 1:                             # zero-insertion: dY on the input's time grid, then the stride-1 data gradient
-                dyu = dy.new_zeros(xd.size(0), xd.size(1), dy.size(2))
-                dyu[:, 0:(dy.size(1) - 1) * stride + 1:stride] = dy
-            dx = K.conv1d_cl_raw(dyu, WA.bwd_operand(R), None, mg_src=xs if in_slope != 1.0 else None, lengths=ctx.lengths, dil=dil,
-                                 pad=dil * (k - 1) - pad, mg_slope=in_slope, flags=K.CONV_MASK_OUT if mask_in else 0)
+            # stride > 1: the kernel walks dY on the input's time grid phase by phase (in_div), no zero-insertion
+            dx = K.conv1d_cl_raw(dy, WA.bwd_operand(R), None, mg_src=xs if in_slope != 1.0 else None, lengths=ctx.lengths, dil=dil,
+                                 pad=dil * (k - 1) - pad, mg_slope=in_slope, flags=K.CONV_MASK_OUT if mask_in else 0,
+                                 in_div=stride, t_out=xd.size(1) if stride != 1 else None)
             if dx.dtype != ctx.x_dtype:
                 dx = dx.to(ctx.x_dtype)
         dres = None

@@ -6,7 +6,7 @@ import torch.nn.functional as F
 
 
 def conv1d_cl_raw(x, w, bias=None, bias_b=None, res=None, mg_src=None, out=None, lengths=None, dil=1, pad=0, stride=1,
-                  in_slope=1.0, mg_slope=1.0, out_scale=1.0, flags=0, gate_h=0, out2=None, out_slope=None):
+                  in_slope=1.0, mg_slope=1.0, out_scale=1.0, flags=0, gate_h=0, out2=None, out_slope=None, in_div=1, t_out=None):
     b, t, c_in = x.shape
     if w.dim() == 4:                       # batched product: one [c_out][c_in] operand per item
         assert w.size(0) == b and w.size(1) == 1
@@ -28,7 +28,17 @@ def conv1d_cl_raw(x, w, bias=None, bias_b=None, res=None, mg_src=None, out=None,
         xf = xf * (torch.arange(t, device=x.device)[None, :, None] < lengths[:, None, None])
     if in_slope != 1.0:
         xf = F.leaky_relu(xf, in_slope)
-    v = F.conv1d(xf.transpose(1, 2), w.float().permute(1, 2, 0), None, stride, pad, dil).transpose(1, 2)
+    if in_div > 1:                         # data gradient of a strided convolution: tap j reads x[(u + j*dil - pad) / in_div]
+        assert stride == 1 and not (flags & (32 | 64))
+        u = torch.arange(t_out, device=x.device)
+        v = torch.zeros(b, t_out, c_out, device=x.device)
+        for j in range(k):
+            num = u + j * dil - pad
+            ok = (num >= 0) & (num % in_div == 0) & (num // in_div < t)
+            rows = xf[:, (num // in_div).clamp(0, t - 1)] * ok[None, :, None]
+            v = v + rows @ w[j].float().t()
+    else:
+        v = F.conv1d(xf.transpose(1, 2), w.float().permute(1, 2, 0), None, stride, pad, dil).transpose(1, 2)
     if bias is not None:
         v = v + bias
     if bias_b is not None:
@@ -135,7 +145,9 @@ def weight_prep(arena):
             v = v * (s.g.detach().float() / torch.linalg.vector_norm(v, 2, dim=tuple(range(1, v.dim())), keepdim=True))
         if getattr(s, "torch_layout", False):
             f.copy_(v.to(f.dtype))
-        elif s.transpose:                                   # [c_in][c_out][k] -> [1][k*c_out][c_in_p]
+            continue
+        v = v.reshape(v.shape[:3])                          # Conv2d (k, 1) weights are read as [c_out][c_in][k]
+        if s.transpose:                                   # [c_in][c_out][k] -> [1][k*c_out][c_in_p]
             w = v.permute(2, 1, 0).reshape(1, s.k * s.c_out, s.c_in)
             f.zero_(); f[:, :, : s.c_in] = w.to(f.dtype)
             bw.zero_(); bw[:, : s.c_in, :] = w.transpose(1, 2).to(bw.dtype)
@@ -162,6 +174,7 @@ def weight_prep_bwd(arena):
             dw = dwv[:, : s.n_rows, : s.c_in].permute(1, 2, 0)                              # [rows][c_in][k]
             rows = slice(s.row_lo, s.row_lo + s.n_rows)
         vr = v[rows]
+        dw = dw.reshape(vr.shape)                            # Conv2d (k, 1): trailing unit axis
         if s.g is None:
             arena.dparam_views[pid[id(s.v)]][rows] = dw
         else:

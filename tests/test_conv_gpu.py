@@ -183,3 +183,46 @@ def test_emulation_agrees_on_new_modes(pkg, dtype, tol):
     ga = K.conv1d_cl_wgrad_raw(wide[..., :H], dyw[..., H:], 1)
     gb = cl_emul.conv1d_cl_wgrad_raw(wide[..., :H], dyw[..., H:], 1)
     assert rel(ga, gb) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-5), (torch.bfloat16, 1.5e-2)])
+def test_flat_row_kernel_and_strided_data_gradient(pkg, dtype, tol):
+    """csrc/conv1d_flat.hip: rows enumerate (item, time) pairs (period-discriminator shapes: many short items, stride 3)
+    and the data gradient of a strided convolution walks dY phase by phase (in_div) instead of zero-insertion."""
+    import cl_emul
+    K = pkg.kernels
+    torch.manual_seed(5)
+    for (b, t, ci, co, kk, st, pd) in [(48, 57, 32, 128, 5, 3, 2), (33, 19, 128, 512, 5, 3, 2), (80, 7, 1024, 1024, 5, 1, 2),
+                                       (16, 40, 64, 32, 3, 1, 1), (5, 301, 32, 96, 41, 4, 20)]:
+        x = torch.randn(b, t, ci, device=DEV).to(dtype)
+        w = (torch.randn(kk, co, ci, device=DEV) / (ci * kk) ** 0.5).to(dtype)
+        bias = torch.randn(co, device=DEV)
+        lens = torch.randint(1, t + 1, (b,), device=DEV, dtype=torch.int32)
+        kw = dict(bias=bias, pad=pd, stride=st, in_slope=0.1, out_slope=0.2, lengths=lens, flags=K.CONV_MASK_IN | K.CONV_FLAT)
+        kwe = dict(kw, flags=K.CONV_MASK_IN)
+        ya, yb = K.conv1d_cl_raw(x, w, **kw), cl_emul.conv1d_cl_raw(x, w, **kwe)
+        assert ya.shape == yb.shape and rel(ya, yb) < tol, (b, t, ci, co, kk, st)
+        # residual + accumulate epilogues through the flat kernel
+        r = torch.randn_like(ya)
+        oa, ob = ya.clone(), yb.clone()
+        K.conv1d_cl_raw(x, w, res=r, out=oa, pad=pd, stride=st, flags=K.CONV_ACCUM | K.CONV_FLAT, out_scale=0.5)
+        cl_emul.conv1d_cl_raw(x, w, res=r, out=ob, pad=pd, stride=st, flags=K.CONV_ACCUM, out_scale=0.5)
+        assert rel(oa, ob) < tol
+        # data gradient: dx = conv(dy, flipped w^T) on the input grid, divided index
+        dy = torch.randn_like(ya)
+        wb = w.flip(0).transpose(1, 2).contiguous()
+        xf = x.float().requires_grad_(True)
+        yr = torch.nn.functional.conv1d(xf.transpose(1, 2), w.float().permute(1, 2, 0), None, st, pd).transpose(1, 2)
+        (dx_ref,) = torch.autograd.grad(yr, xf, dy.float())
+        dxa = K.conv1d_cl_raw(dy, wb, pad=kk - 1 - pd, in_div=st, t_out=t) if st > 1 else K.conv1d_cl_raw(dy, wb, pad=kk - 1 - pd, flags=K.CONV_FLAT)
+        assert dxa.shape == dx_ref.shape and rel(dxa, dx_ref) < tol, ("dgrad", b, t, ci, co, kk, st)
+        if st > 1:
+            dxe = cl_emul.conv1d_cl_raw(dy, wb, pad=kk - 1 - pd, in_div=st, t_out=t)
+            assert rel(dxe, dx_ref) < tol
+        # weight + bias gradient, flat-row variant (masked rows on both sides)
+        if kk <= 5:
+            dba, dbb = torch.empty(co, device=DEV), torch.empty(co, device=DEV)
+            fl = K.CONV_MASK_IN | (K.CONV_MASK_OUT if st == 1 else 0)
+            ga = K.conv1d_cl_wgrad_raw(x, dy, kk, lengths=lens, pad=pd, stride=st, in_slope=0.1, flags=fl | K.CONV_FLAT, dbias=dba)
+            gb = cl_emul.conv1d_cl_wgrad_raw(x, dy, kk, lengths=lens, pad=pd, stride=st, in_slope=0.1, flags=fl, dbias=dbb)
+            assert rel(ga, gb) < tol and rel(dba, dbb) < tol, ("wgrad", b, t, ci, co, kk, st)

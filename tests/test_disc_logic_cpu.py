@@ -37,10 +37,13 @@ def test_discriminator_p(emulated, period):
         assert rel_err(p.grad, sd["d." + k].grad) < 5e-5, k
 
 
-def test_mpd_library_path_through_arena(emulated):
-    """MultiPeriodDiscriminator on the library-convolution path with the weight-norm of all 37 layers coming from
-    the arena (torch-layout operands): outputs and parameter gradients equal the oracle."""
+@pytest.mark.parametrize("hip_p", [False, True])
+def test_mpd_through_arena(emulated, monkeypatch, hip_p):
+    """MultiPeriodDiscriminator with the weight-norm of all 37 layers coming from the arena — period discriminators on
+    the channels-last kernels (hip_p) or everything on library convolutions with torch-layout operands: outputs and
+    parameter gradients equal the oracle."""
     pkg = emulated
+    monkeypatch.setattr(pkg.models.DiscriminatorP, "use_hip", hip_p)
     torch.manual_seed(0)
     d = pkg.MultiPeriodDiscriminator(False)
     sd = {k: v.detach().clone().requires_grad_(True) for k, v in d.state_dict().items()}

@@ -135,3 +135,20 @@ def test_period_discriminator_hip_path(pkg):
     assert rel_err(xa.grad, xb.grad) < 1e-3
     for k, p in d.named_parameters():
         assert rel_err(p.grad, sd["d." + k].grad) < 1e-3, k
+
+
+def test_captured_step_replays_reproducibly(pkg):
+    """The whole fine-tune step captured as one hipGraph: two replays from the same state give the same losses and
+    parameters, and agree with the eager step (FineTuner.verify_replay) — the guard bench.py runs before timing."""
+    from importlib import import_module
+    cfgs = import_module("personalized_text-to-speech_amd.configs")
+    tr = import_module("personalized_text-to-speech_amd.train")
+    hps = cfgs.get("modified_finetune_speaker")
+    ft = tr.FineTuner(hps, "cuda:0", amp=True)
+    batch = tr.synthetic_batch(hps, 4, (100, 160), "cuda:0")
+    ft.capture(batch, warmup=2)
+    losses = ft.verify_replay()
+    assert all(np.isfinite(list(losses.values())))
+    for _ in range(3):
+        out = ft.replay()
+    assert all(np.isfinite([float(v) for v in out.values()]))
