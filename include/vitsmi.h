@@ -124,7 +124,9 @@ typedef struct vits_conv_desc {
   int32_t in_div;           /* > 1: data gradient of a stride-`in_div` convolution (stride must be 1): the input time of
                                tap j for output t is (t + j*dil - pad) / in_div when divisible, else the tap is zero      */
   int32_t t_out_override;   /* output length when in_div > 1 (= the forward convolution's input length)                */
-  int32_t reserved1;
+  int32_t groups;           /* > 1: grouped convolution given as DENSE block-diagonal operands w [k][c_out][c_in] (what
+                               vits_weight_prep layout 3 writes): the kernel only walks the input channels a tile of output
+                               channels can see.  Flat-row kernel only.                                                  */
   int64_t w_batch_stride;   /* elements between the operands of consecutive batch items; 0 = one shared w:
                                with k = 1 this makes the call a batched product Y[b] = X[b] . W[b]^T (attention) */
   float in_slope, mg_slope, out_scale, out_slope;
@@ -146,7 +148,9 @@ typedef struct vits_wgrad_desc {
   int32_t dtype;            /* dtype of x and dy                                                          */
   int32_t b, t, c_in, c_out, k, dil, pad, stride, flags;
   int32_t ldx, lddy;        /* row pitches of x and dy (0 = dense)                                        */
-  float in_slope, reserved;
+  float in_slope;
+  int32_t groups;           /* > 1: grouped convolution (see vits_conv_desc.groups): only the block-diagonal part is computed and
+                               dw is the COMPACT float32 [k][c_out][c_in/groups]                                        */
   const void* x;  const void* dy;  float* dw;  void* workspace;  size_t workspace_bytes;
   const int32_t* lengths;
   float* dbias;             /* optional float32[c_out]: (+)= sum_{b,t} dy[b][t][co] (rows masked like dy), same launch */
@@ -183,7 +187,9 @@ int vits_convt_unfold_cl(int dtype, const void* dy, void* dp, int b, int t_in, i
  *   entries  device array, one per (slice of a) convolution weight, sorted by row0:
  *     v        fp32 master weight in torch layout: Conv1d [c_out_total][c_in][k] (layout 0) or
  *              ConvTranspose1d [c_in_total][c_out][k] (layout 1); layout 2 = Conv1d whose operand keeps the torch
- *              layout (weight-norm + dtype only; consumed by a library convolution);  g  weight_g [rows_total] or NULL;
+ *              layout (weight-norm + dtype only; consumed by a library convolution); layout 3 = grouped Conv1d
+ *              [c_out][c_in/groups][k] emitted as DENSE block-diagonal operands (only the diagonal blocks are written: the
+ *              arenas are allocated zeroed), its dw is the compact [k][c_out][c_in/groups];  g  weight_g [rows_total] or NULL;
  *     row_lo   first weight-norm row of the parameter covered by this entry, n_rows rows are covered
  *              (layout 0: rows are output channels, c_out = n_rows; layout 1: rows are input channels);
  *     c_out_p / c_in_p   padded channel counts of the emitted operands (zero outside; pad areas are
@@ -196,7 +202,7 @@ int vits_convt_unfold_cl(int dtype, const void* dy, void* dp, int b, int t_in, i
 typedef struct vits_prep_entry {
   const float* v;  const float* g;
   int64_t off, off_dv, off_dg;
-  int32_t layout, c_out, c_in, k, c_out_p, c_in_p, row_lo, n_rows, row0, reserved;
+  int32_t layout, c_out, c_in, k, c_out_p, c_in_p, row_lo, n_rows, row0, groups;
 } vits_prep_entry;
 
 int vits_weight_prep(const vits_prep_entry* entries, int n_entries, int total_rows, int dtype, void* w_fwd,

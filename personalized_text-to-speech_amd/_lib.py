@@ -10,7 +10,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvitsmi.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 c_int = ctypes.c_int
 c_void_p = ctypes.c_void_p
@@ -44,7 +44,7 @@ SIGNATURES = {
 class ConvDesc(ctypes.Structure):
     """vits_conv_desc of include/vitsmi.h"""
     _fields_ = [(n, ctypes.c_int32) for n in ("dtype", "b", "t", "c_in", "c_out", "k", "dil", "pad", "stride", "flags",
-                                              "ldx", "ldy", "ldy2", "gate_h", "ldw", "in_div", "t_out_override", "reserved1")] + \
+                                              "ldx", "ldy", "ldy2", "gate_h", "ldw", "in_div", "t_out_override", "groups")] + \
                [("w_batch_stride", ctypes.c_int64)] + \
                [(n, c_float) for n in ("in_slope", "mg_slope", "out_scale", "out_slope")] + \
                [(n, c_void_p) for n in ("x", "w", "bias", "bias_b", "res", "mg_src", "y", "y2", "lengths")]
@@ -53,14 +53,14 @@ class ConvDesc(ctypes.Structure):
 class PrepEntry(ctypes.Structure):
     """vits_prep_entry of include/vitsmi.h"""
     _fields_ = [("v", c_void_p), ("g", c_void_p), ("off", ctypes.c_int64), ("off_dv", ctypes.c_int64), ("off_dg", ctypes.c_int64)] + \
-               [(n, ctypes.c_int32) for n in ("layout", "c_out", "c_in", "k", "c_out_p", "c_in_p", "row_lo", "n_rows", "row0", "reserved")]
+               [(n, ctypes.c_int32) for n in ("layout", "c_out", "c_in", "k", "c_out_p", "c_in_p", "row_lo", "n_rows", "row0", "groups")]
 
 
 class WgradDesc(ctypes.Structure):
     """vits_wgrad_desc of include/vitsmi.h"""
     _fields_ = [(n, ctypes.c_int32) for n in ("dtype", "b", "t", "c_in", "c_out", "k", "dil", "pad", "stride", "flags",
                                               "ldx", "lddy")] + \
-               [(n, c_float) for n in ("in_slope", "reserved")] + \
+               [("in_slope", c_float), ("groups", ctypes.c_int32)] + \
                [("x", c_void_p), ("dy", c_void_p), ("dw", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_size_t),
                 ("lengths", c_void_p), ("dbias", c_void_p)]
 

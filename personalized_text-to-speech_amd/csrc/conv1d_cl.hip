@@ -379,7 +379,8 @@ extern "C" int vits_conv1d_cl(const vits_conv_desc* desc, void* stream) {
   // flat-row kernel: strided / divided launches, and short sequences spread over many items (most of a per-item
   // time tile would be empty).  It has no gate epilogues and no per-item operands.
   const bool flat_ok = !gate && !gate_bwd && d.w_batch_stride == 0 && d.y2 == nullptr;
-  const bool must_flat = in_div > 1 || (d.flags & VITS_CONV_FLAT) != 0;
+  if (d.groups > 1 && (d.c_out % d.groups != 0 || d.c_in % d.groups != 0)) return VITS_E_BADARG;
+  const bool must_flat = in_div > 1 || (d.flags & VITS_CONV_FLAT) != 0 || d.groups > 1;
   if (must_flat && !flat_ok) return VITS_E_UNSUPPORTED;
   static const bool auto_flat = !(getenv("VITS_FLAT_AUTO") && getenv("VITS_FLAT_AUTO")[0] == '0');
   if (must_flat || (flat_ok && (d.stride > 1 || (auto_flat && t_out <= 80 && d.b >= 8)))) {

@@ -35,6 +35,7 @@ struct WgradArgs {
   float in_slope;
   int flags;
   int ldx, lddy, stride;
+  int groups;             // > 1: block-diagonal only, compact dw [k][c_out][c_in/groups]
   float* partial_db;      // per-split bias-gradient sums (slab pitch `slab`), or null
   size_t slab;            // floats per split in `partial` (dw slab, optionally followed by the db slab)
 };
@@ -81,8 +82,11 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wi = SMALL ? 0 : (wave >> 1), wj = SMALL ? 0 : (wave & 1);
   const int r = lane & 31, h = lane >> 5;
-  const int n_ci_tiles = (a.Cin + CT - 1) / CT;
-  const int co0 = blockIdx.y * CT, ci0 = (blockIdx.z % n_ci_tiles) * CT;
+  const int n_ci_tiles = a.groups > 1 ? 1 : (a.Cin + CT - 1) / CT;
+  const int co0 = blockIdx.y * CT;
+  const int og = a.groups > 1 ? a.Cout / a.groups : 1, ig = a.groups > 1 ? a.Cin / a.groups : 1;
+  // grouped: the one ci tile that holds this co tile's diagonal blocks (host guarantees it is a single tile)
+  const int ci0 = a.groups > 1 ? ((co0 / og) * ig / CT) * CT : (blockIdx.z % n_ci_tiles) * CT;
   const int tap0 = (blockIdx.z / n_ci_tiles) * KT;
   const int ntap = (a.K - tap0 < KT) ? (a.K - tap0) : KT;
   // FLAT: chunks are TK consecutive rows of the joint (item, time) index and every tap has its own gathered
@@ -291,7 +295,13 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int co = co0 + wi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-          if (co < a.Cout) P[((size_t)(tap0 + k) * a.Cout + co) * a.Cin + ci] = acc[k][i];
+          if (co >= a.Cout) continue;
+          if (a.groups > 1) {
+            const int ci_lo = (co / og) * ig;
+            if (ci >= ci_lo && ci < ci_lo + ig) P[((size_t)(tap0 + k) * a.Cout + co) * ig + (ci - ci_lo)] = acc[k][i];
+          } else {
+            P[((size_t)(tap0 + k) * a.Cout + co) * a.Cin + ci] = acc[k][i];
+          }
         }
       }
   }
@@ -347,7 +357,7 @@ int launch(const WgradArgs& a, hipStream_t s) {
     if (e != hipSuccess) return vits::note_hip_error(e, "vits_conv1d_cl_wgrad/attr");
     lds_attr_set = true;
   }
-  dim3 grid(a.S, vits::ceil_div(a.Cout, CT), vits::ceil_div(a.Cin, CT) * vits::ceil_div(a.K, KT));
+  dim3 grid(a.S, vits::ceil_div(a.Cout, CT), (a.groups > 1 ? 1 : vits::ceil_div(a.Cin, CT)) * vits::ceil_div(a.K, KT));
   hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, s, a);
   return vits::check_launch("vits_conv1d_cl_wgrad");
 }
@@ -387,20 +397,28 @@ extern "C" int vits_conv1d_cl_wgrad(const vits_wgrad_desc* desc, void* stream) {
   if (span < 0) return VITS_E_BADARG;
   const int t_out = span / d.stride + 1;
   if (((d.flags & (VITS_CONV_MASK_IN | VITS_CONV_MASK_OUT)) != 0) && !d.lengths) return VITS_E_BADARG;
-  if (d.workspace_bytes < vits_conv1d_cl_wgrad_workspace(d.b, t_out, d.c_in, d.c_out, d.k)) return VITS_E_BADARG;
+  // grouped: splits and slabs are sized by the compact dw, i.e. call the workspace function with c_in / groups
+  const int c_in_eff = d.groups > 1 ? d.c_in / d.groups : d.c_in;
+  if (d.workspace_bytes < vits_conv1d_cl_wgrad_workspace(d.b, t_out, c_in_eff, d.c_out, d.k)) return VITS_E_BADARG;
   if (d.ldx <= 0) d.ldx = d.c_in;
   if (d.lddy <= 0) d.lddy = d.c_out;
   // flat-row variant: strided layers and many short items (same rule as vits_conv1d_cl); never more splits than the
   // per-item variant, so the workspace bound above holds for both
   static const bool auto_flat = !(getenv("VITS_FLAT_AUTO") && getenv("VITS_FLAT_AUTO")[0] == '0');
-  const bool flat = d.stride > 1 || (d.flags & VITS_CONV_FLAT) != 0 || (auto_flat && t_out <= 80 && d.b >= 8);
-  const int S = pick_splits(d.b, t_out, d.c_in, d.c_out, d.k, flat);
-  const size_t n = (size_t)d.k * d.c_out * d.c_in, nb = d.dbias ? (size_t)d.c_out : 0;   // multiples of 4
+  if (d.groups > 1) {
+    // block-diagonal tiles only: a 64-wide co tile must map into ONE 64-wide ci tile
+    if (d.c_out % d.groups != 0 || d.c_in % d.groups != 0) return VITS_E_BADARG;
+    const int og = d.c_out / d.groups, ig = d.c_in / d.groups;
+    if (ig > og || CT % og != 0 || CT % ((CT / og) * ig) != 0) return VITS_E_UNSUPPORTED;
+  }
+  const bool flat = d.groups > 1 || d.stride > 1 || (d.flags & VITS_CONV_FLAT) != 0 || (auto_flat && t_out <= 80 && d.b >= 8);
+  const int S = pick_splits(d.b, t_out, c_in_eff, d.c_out, d.k, flat);
+  const size_t n = (size_t)d.k * d.c_out * (d.groups > 1 ? d.c_in / d.groups : d.c_in), nb = d.dbias ? (size_t)d.c_out : 0;   // multiples of 4
   const bool accumulate = (d.flags & VITS_CONV_ACCUM) != 0;
   const bool direct = (S == 1) && !accumulate;           // a single split writes dw / db itself: no second launch
   float* ws = static_cast<float*>(d.workspace);
   WgradArgs a{d.x, d.dy, direct ? d.dw : ws, d.lengths, d.b, d.t, t_out, d.c_in, d.c_out, d.k, d.dil, d.pad,
-              S, vits::ceil_div(t_out, TK), d.in_slope, d.flags, d.ldx, d.lddy, d.stride,
+              S, vits::ceil_div(t_out, TK), d.in_slope, d.flags, d.ldx, d.lddy, d.stride, d.groups,
               d.dbias ? (direct ? d.dbias : ws + n) : nullptr, direct ? 0 : n + nb};
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc;

@@ -118,7 +118,16 @@ __global__ __launch_bounds__(kThreads) void conv1d_flat_kernel(FlatArgs args) {
     for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
 
   const int n_groups = (n_taps + args.G - 1) / args.G;
-  const int n_chunks = (a.c_in + KC - 1) / KC;
+  // grouped convolution on dense block-diagonal operands: this tile of output channels only sees the input
+  // channels of its own groups
+  int ci_begin = 0, ci_end = a.c_in;
+  if (a.groups > 1) {
+    const int og = a.c_out / a.groups, ig = a.c_in / a.groups;
+    const int co_last = (co0 + TN < a.c_out ? co0 + TN : a.c_out) - 1;
+    ci_begin = ((co0 / og) * ig / KC) * KC;
+    ci_end = (co_last / og + 1) * ig;
+  }
+  const int n_chunks = (ci_end - ci_begin + KC - 1) / KC;
   const int n_stages = n_groups * n_chunks;
 
   u32x4 xr[XVF], wr[WVF];
@@ -172,13 +181,13 @@ __global__ __launch_bounds__(kThreads) void conv1d_flat_kernel(FlatArgs args) {
     }
   };
 
-  if (n_stages > 0) { load_stage(0, 0); store_stage(0); }
+  if (n_stages > 0) { load_stage(ci_begin, 0); store_stage(0); }
   __syncthreads();
   for (int s = 0; s < n_stages; ++s) {
     const int g0 = (s % n_groups) * args.G;
     const int nxt = s + 1;
     const bool has_next = nxt < n_stages;
-    const int ng0 = (nxt % n_groups) * args.G, nci0 = (nxt / n_groups) * KC;
+    const int ng0 = (nxt % n_groups) * args.G, nci0 = ci_begin + (nxt / n_groups) * KC;
     if (has_next) load_stage(nci0, ng0);
     const int ntap = (n_taps - g0 < args.G) ? (n_taps - g0) : args.G;
     for (int tl = 0; tl < ntap; ++tl) {

@@ -47,6 +47,7 @@ __device__ __forceinline__ Idx locate(const vits_prep_entry& e, int r, int inner
   Idx x;
   if (e.layout != 1) {            // Conv1d [c_out][c_in][k]: row = co (within the entry), inner = ci*k + tap
     x.co = r; x.ci = inner / e.k; x.tap = inner % e.k;
+    if (e.layout == 3) x.ci += (r / (e.c_out / e.groups)) * (e.c_in / e.groups);   // grouped: channel inside the dense operand
   } else {                        // ConvTranspose1d [c_in][c_out][k]: row = ci, inner = co*k + j
     x.ci = r; x.co = inner / e.k; x.tap = inner % e.k;
   }
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(256) void prep_fwd(const vits_prep_entry* __restric
   __shared__ float red[4];
   const vits_prep_entry e = ents[find_entry(ents, n_ents, blockIdx.x)];
   const int r = blockIdx.x - e.row0;                         // row within the entry
-  const int inner = (e.layout == 1) ? e.c_out * e.k : e.c_in * e.k;
+  const int inner = (e.layout == 1) ? e.c_out * e.k : (e.layout == 3 ? (e.c_in / e.groups) * e.k : e.c_in * e.k);
   const float* v = e.v + ((size_t)(e.row_lo + r)) * inner;
   float scale = 1.f;
   if (e.g) {
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(256) void prep_fwd(const vits_prep_entry* __restric
     const float val = v[i] * scale;
     if (e.layout == 2) {                  // torch layout kept (consumer is a MIOpen convolution): only weight-norm + dtype
       put<T>(w_fwd, e.off + (size_t)r * inner + i, val);
-    } else if (e.layout == 0) {
+    } else if (e.layout == 0 || e.layout == 3) {
       put<T>(w_fwd, e.off + ((size_t)x.tap * e.c_out_p + x.co) * e.c_in_p + x.ci, val);
       put<T>(w_bwd, e.off + ((size_t)(e.k - 1 - x.tap) * e.c_in_p + x.ci) * e.c_out_p + x.co, val);
     } else {
@@ -89,11 +90,12 @@ __global__ __launch_bounds__(256) void prep_bwd(const vits_prep_entry* __restric
   __shared__ float red[4];
   const vits_prep_entry e = ents[find_entry(ents, n_ents, blockIdx.x)];
   const int r = blockIdx.x - e.row0;
-  const int inner = (e.layout == 1) ? e.c_out * e.k : e.c_in * e.k;
+  const int inner = (e.layout == 1) ? e.c_out * e.k : (e.layout == 3 ? (e.c_in / e.groups) * e.k : e.c_in * e.k);
   const float* v = e.v + ((size_t)(e.row_lo + r)) * inner;
   float* dv = dparam + e.off_dv + ((size_t)(e.row_lo + r)) * inner;
   auto dw_at = [&](int i) -> float {
     if (e.layout == 2) return dw[e.off + (size_t)r * inner + i];
+    if (e.layout == 3) return dw[e.off + ((size_t)(i % e.k) * e.c_out + r) * (e.c_in / e.groups) + i / e.k];   // compact [k][c_out][Ig]
     const Idx x = locate(e, r, i);
     if (e.layout == 0) return dw[e.off + ((size_t)x.tap * e.c_out_p + x.co) * e.c_in_p + x.ci];
     return dw[e.off + ((size_t)x.tap * e.c_out + x.co) * e.c_in_p + x.ci];

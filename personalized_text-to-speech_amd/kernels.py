@@ -188,7 +188,7 @@ def _rows(t, name):
 
 
 def conv1d_cl_raw(x, w, bias=None, bias_b=None, res=None, mg_src=None, out=None, lengths=None, dil=1, pad=0, stride=1,
-                  in_slope=1.0, mg_slope=1.0, out_scale=1.0, flags=0, gate_h=0, out2=None, out_slope=None, in_div=1, t_out=None):
+                  in_slope=1.0, mg_slope=1.0, out_scale=1.0, flags=0, gate_h=0, out2=None, out_slope=None, in_div=1, t_out=None, groups=1):
     """Launch vits_conv1d_cl.  x [b,t,c_in], w [k,c_out,c_in] (tap-major) in the same dtype; see
     include/vitsmi.h for the fused prologue/epilogue.  Returns y (allocated unless `out` is given)."""
     _lib.require_cuda(x, w)
@@ -223,7 +223,7 @@ def conv1d_cl_raw(x, w, bias=None, bias_b=None, res=None, mg_src=None, out=None,
         flags |= CONV_OUT_LRELU
     d = _lib.ConvDesc(dtype=_DT[x.dtype], b=b, t=t, c_in=c_in, c_out=c_out, k=k, dil=dil, pad=pad, stride=stride, flags=int(flags),
                       ldx=_rows(x, "x"), ldy=ldy, ldy2=0 if out2 is None else _rows(out2, "out2"), gate_h=gate_h,
-                      ldw=ldw, in_div=in_div, t_out_override=(t_out if in_div > 1 else 0), reserved1=0, w_batch_stride=wbs,
+                      ldw=ldw, in_div=in_div, t_out_override=(t_out if in_div > 1 else 0), groups=groups, w_batch_stride=wbs,
                       in_slope=float(in_slope), mg_slope=float(mg_slope), out_scale=float(out_scale), out_slope=float(out_slope or 0.0),
                       x=x.data_ptr(), w=w.data_ptr(), bias=p(bias), bias_b=p(bias_b), res=p(res), mg_src=p(mg_src),
                       y=out.data_ptr(), y2=p(out2), lengths=p(lengths))
@@ -232,7 +232,7 @@ def conv1d_cl_raw(x, w, bias=None, bias_b=None, res=None, mg_src=None, out=None,
     rc = _lib.lib().vits_conv1d_cl(ctypes.addressof(d), _lib.stream_ptr())
     if e0 is not None:                                         # units = (FLOP, algorithmic bytes: x + y + w read/written once)
         es = x.element_size()
-        _lib.timer.stop("vits_conv1d_cl", e0, (2.0 * b * t_out * c_out * c_in * k,
+        _lib.timer.stop("vits_conv1d_cl", e0, (2.0 * b * t_out * c_out * (c_in // groups) * k,
                                                 es * (b * t * c_in + b * t_out * out.size(2) + k * c_out * c_in + (0 if res is None else res.numel()))),
                         shape=f"b{b} t{t} ci{c_in} co{c_out} k{k} d{dil} s{stride}/{in_div} f{flags} {str(x.dtype)[6:]}")
     _lib.check(rc, "vits_conv1d_cl")
@@ -251,7 +251,7 @@ def workspace(nbytes, device):
     return buf
 
 
-def conv1d_cl_wgrad_raw(x, dy, k, lengths=None, dil=1, pad=0, stride=1, in_slope=1.0, flags=0, out=None, dbias=None):
+def conv1d_cl_wgrad_raw(x, dy, k, lengths=None, dil=1, pad=0, stride=1, in_slope=1.0, flags=0, out=None, dbias=None, groups=1):
     """dW [k, c_out, c_in] float32 of conv1d_cl_raw(x, w, ...) given dy [b, t_out, c_out]; optionally the bias
     gradient (column sums of dy) into `dbias` float32 [c_out] in the same launch."""
     _lib.require_cuda(x, dy)
@@ -260,15 +260,16 @@ def conv1d_cl_wgrad_raw(x, dy, k, lengths=None, dil=1, pad=0, stride=1, in_slope
     c_out = dy.shape[2]
     t_out = (t + 2 * pad - dil * (k - 1) - 1) // stride + 1
     assert tuple(dy.shape[:2]) == (b, t_out), (tuple(x.shape), tuple(dy.shape))
+    c_in_w = c_in // groups                   # grouped: compact dw [k][c_out][c_in / groups]
     if out is None:
         assert not (flags & CONV_ACCUM)
-        out = torch.empty((k, c_out, c_in), device=x.device, dtype=torch.float32)
-    assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (k, c_out, c_in)
+        out = torch.empty((k, c_out, c_in_w), device=x.device, dtype=torch.float32)
+    assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (k, c_out, c_in_w)
     L = _lib.lib()
-    ws_bytes = L.vits_conv1d_cl_wgrad_workspace(b, t_out, c_in, c_out, k)
+    ws_bytes = L.vits_conv1d_cl_wgrad_workspace(b, t_out, c_in_w, c_out, k)
     ws = workspace(ws_bytes, x.device)
     d = _lib.WgradDesc(dtype=_DT[x.dtype], b=b, t=t, c_in=c_in, c_out=c_out, k=k, dil=dil, pad=pad, stride=stride, flags=int(flags),
-                       ldx=_rows(x, "x"), lddy=_rows(dy, "dy"), in_slope=float(in_slope), reserved=0.0,
+                       ldx=_rows(x, "x"), lddy=_rows(dy, "dy"), in_slope=float(in_slope), groups=groups,
                        x=x.data_ptr(), dy=dy.data_ptr(), dw=out.data_ptr(), workspace=ws.data_ptr(), workspace_bytes=ws.numel(),
                        lengths=None if lengths is None else lengths.data_ptr(),
                        dbias=None if dbias is None else dbias.data_ptr())
@@ -278,8 +279,8 @@ def conv1d_cl_wgrad_raw(x, dy, k, lengths=None, dil=1, pad=0, stride=1, in_slope
     rc = L.vits_conv1d_cl_wgrad(ctypes.addressof(d), _lib.stream_ptr())
     if e0 is not None:
         es = x.element_size()
-        _lib.timer.stop("vits_conv1d_cl_wgrad", e0, (2.0 * b * t_out * c_out * c_in * k,
-                                                      es * (b * t * c_in + b * t_out * c_out) + 4.0 * k * c_out * c_in),
+        _lib.timer.stop("vits_conv1d_cl_wgrad", e0, (2.0 * b * t_out * c_out * c_in_w * k,
+                                                      es * (b * t * c_in + b * t_out * c_out) + 4.0 * k * c_out * c_in_w),
                         shape=f"b{b} t{t} ci{c_in} co{c_out} k{k} d{dil} s{stride} {str(x.dtype)[6:]}")
     _lib.check(rc, "vits_conv1d_cl_wgrad")
     return out

@@ -359,6 +359,18 @@ class DiscriminatorP(nn.Module):
         return torch.flatten(y, 1, -1), fmap
 
 
+def _dense_grouped_weight(l, pad_in=0):
+    """Kernel-layout [k][c_out][c_in] operand of a (possibly grouped) Conv1d, block-diagonal, autograd-connected."""
+    w = l.weight                                                          # [c_out][c_in/groups][k]
+    if l.groups > 1:
+        og = w.size(0) // l.groups
+        ig = w.size(1)
+        w = torch.cat([F.pad(w[g * og:(g + 1) * og], (0, 0, g * ig, (l.groups - 1 - g) * ig)) for g in range(l.groups)], 0)
+    if pad_in:
+        w = F.pad(w, (0, 0, 0, pad_in))
+    return w.permute(2, 0, 1).contiguous()
+
+
 class DiscriminatorS(nn.Module):
     # models.py:338-361
     def __init__(self, use_spectral_norm=False):
@@ -371,7 +383,13 @@ class DiscriminatorS(nn.Module):
             WNConv1d(1024, 1024, 41, 4, groups=256, padding=20), WNConv1d(1024, 1024, 5, 1, padding=2)])
         self.conv_post = WNConv1d(1024, 1, 3, 1, padding=1)
 
+    # VITS_DISC_S=library selects the MIOpen convolutions (A/B measurements only)
+    use_hip = os.environ.get("VITS_DISC_S", "hip") != "library"
+
     def forward(self, x):
+        return self.forward_hip(x) if DiscriminatorS.use_hip else self.forward_rocm(x)
+
+    def forward_rocm(self, x):
         fmap = []
         for i, l in enumerate(self.convs):
             x = F.leaky_relu(_first_layer_fp32(l, x) if i == 0 else l(x), modules.LRELU_SLOPE)
@@ -379,6 +397,28 @@ class DiscriminatorS(nn.Module):
         x = self.conv_post(x)
         fmap.append(x)
         return torch.flatten(x, 1, -1), fmap
+
+    def forward_hip(self, x):
+        """x [n, 1, t] -> (logits [n, t'], fmap list in the reference's [n, c, t'] layout, as views of channels-last
+        activations).  Every layer runs on the flat-row MFMA kernel with leaky-relu fused; the grouped layers
+        (groups 4..256, 4 input channels per group) take DENSE block-diagonal operands from the weight arena and the
+        kernel only walks the input channels a tile of output channels can see (vits_conv_desc.groups)."""
+        from . import wn_cl, weight_arena as WA
+        dtype = wn_cl.compute_dtype()
+        fmap = []
+        h = F.pad(x.transpose(1, 2), (0, 7)).to(dtype)                   # [n, t, 1] -> c_in 8 (vector width), zero weights there
+        for i, l in enumerate(self.convs):
+            groups = l.groups
+            w = WA.handle_for(l)
+            if w is None:                                                # outside an arena scope: torch-prepared operand
+                w, groups = _dense_grouped_weight(l, 7 if i == 0 else 0), 1
+            h = wn_cl.conv_cl(h, w, l.bias, pad=l.padding, stride=l.stride, out_slope=modules.LRELU_SLOPE, dtype=dtype, groups=groups)
+            fmap.append(h.transpose(1, 2))
+        l = self.conv_post
+        y = wn_cl.conv_cl(h, wn_cl.weight_of(l, pad_out=7), wn_cl.bias_of(l, 7), pad=l.padding, dtype=dtype)[..., :1]
+        y = y.transpose(1, 2)
+        fmap.append(y)
+        return torch.flatten(y, 1, -1), fmap
 
 
 class MultiPeriodDiscriminator(nn.Module):
@@ -413,6 +453,10 @@ class MultiPeriodDiscriminator(nn.Module):
             if isinstance(d, DiscriminatorP) and DiscriminatorP.use_hip:
                 specs.append(Spec(d.convs[0], c_in_p=8))
                 specs += [Spec(l) for l in d.convs[1:]]
+                specs.append(Spec(d.conv_post, c_out_p=8))
+            elif isinstance(d, DiscriminatorS) and DiscriminatorS.use_hip:
+                specs.append(Spec(d.convs[0], c_in_p=8))
+                specs += [Spec(l, groups=l.groups) for l in d.convs[1:]]
                 specs.append(Spec(d.conv_post, c_out_p=8))
             else:           # library (MIOpen) convolutions: weight-norm + dtype for all layers in the same launch
                 specs += [Spec(l, "torch", torch_layout=True) for l in list(d.convs) + [d.conv_post]]

@@ -25,8 +25,8 @@ _registry = {}             # handle.data_ptr() -> (arena, index)
 
 
 class Spec:
-    def __init__(self, module, part=None, row_lo=0, n_rows=None, c_out_p=None, c_in_p=None, transpose=False, torch_layout=False):
-        self.module, self.part, self.transpose, self.torch_layout = module, part, transpose, torch_layout
+    def __init__(self, module, part=None, row_lo=0, n_rows=None, c_out_p=None, c_in_p=None, transpose=False, torch_layout=False, groups=1):
+        self.module, self.part, self.transpose, self.torch_layout, self.groups = module, part, transpose, torch_layout, groups
         has_g = hasattr(module, "weight_g")
         self.v = module.weight_v if has_g else module.weight
         self.g = module.weight_g if has_g else None
@@ -48,6 +48,12 @@ class Spec:
             if torch_layout:                  # operand = weight-normed parameter in its own layout (library convolutions)
                 assert row_lo == 0 and n_rows is None and not c_out_p and not c_in_p
                 self.fwd_shape = self.bwd_shape = tuple(self.v.shape)
+            if groups > 1:                    # grouped Conv1d [c_out][c_in/groups][k] -> dense block-diagonal operands, compact dw
+                assert row_lo == 0 and n_rows is None and not c_out_p and not c_in_p and not torch_layout
+                self.c_in = self.c_in_p = d1 * groups
+                self.numel = k * d0 * self.c_in
+                self.fwd_shape, self.bwd_shape = (k, d0, self.c_in), (k, self.c_in, d0)
+        self.dw_shape = (self.k, self.c_out, self.c_in // groups) if groups > 1 else self.fwd_shape
 
 
 class WeightArena:
@@ -76,7 +82,8 @@ class WeightArena:
             e.v, e.g = s.v.data_ptr(), (s.g.data_ptr() if s.g is not None else None)
             e.off, e.off_dv = off, self.p_off[pidx[id(s.v)]]
             e.off_dg = self.p_off[pidx[id(s.g)]] if s.g is not None else 0
-            e.layout, e.c_out, e.c_in, e.k = (2 if s.torch_layout else (1 if s.transpose else 0)), s.c_out, s.c_in, s.k
+            e.layout, e.c_out, e.c_in, e.k = (3 if s.groups > 1 else (2 if s.torch_layout else (1 if s.transpose else 0))), s.c_out, s.c_in, s.k
+            e.groups = s.groups
             e.c_out_p, e.c_in_p, e.row_lo, e.n_rows, e.row0 = s.c_out_p, s.c_in_p, s.row_lo, s.n_rows, row0
             row0 += s.n_rows
             off += (s.numel + 63) & ~63                         # keep every operand 128-byte aligned
@@ -90,8 +97,11 @@ class WeightArena:
         self.fwd = [view(self.w_fwd, o, s, s.fwd_shape) for o, s in zip(offs, specs)]
         self.bwd = [view(self.w_bwd, o, s, s.bwd_shape) for o, s in zip(offs, specs)]
         # torch-layout operands are consumed by autograd-aware library ops: their handle is the operand itself
-        self.handles = [view(self.w_fwd if s.torch_layout else self.handle, o, s, s.fwd_shape) for o, s in zip(offs, specs)]
-        self.dws = [view(self.dw, o, s, s.fwd_shape) for o, s in zip(offs, specs)]
+        # (grouped specs: the handle has the shape of the compact weight gradient the layer node returns for it)
+        cview = lambda buf, o, s: buf[o:o + s.dw_shape[0] * s.dw_shape[1] * s.dw_shape[2]].view(s.dw_shape)
+        self.handles = [cview(self.handle, o, s) if s.groups > 1 else view(self.w_fwd if s.torch_layout else self.handle, o, s, s.fwd_shape)
+                        for o, s in zip(offs, specs)]
+        self.dws = [cview(self.dw, o, s) if s.groups > 1 else view(self.dw, o, s, s.fwd_shape) for o, s in zip(offs, specs)]
         self.ptrs = [p.data_ptr() for p in self.params]
         for i, h in enumerate(self.handles):
             _registry[h.data_ptr()] = (self, i)

@@ -43,7 +43,7 @@ class ConvCLFn(torch.autograd.Function):
     by the same HIP kernels (in_slope = 0 is a fused ReLU on the input)."""
 
     @staticmethod
-    def forward(ctx, dtype, x, w, bias, lengths, dil, pad, in_slope, mask_in, mask_out, res, stride, out_slope):
+    def forward(ctx, dtype, x, w, bias, lengths, dil, pad, in_slope, mask_in, mask_out, res, stride, out_slope, groups=1):
         xd = x.detach()
         if xd.dtype != dtype:
             xd = xd.to(dtype)
@@ -51,7 +51,8 @@ class ConvCLFn(torch.autograd.Function):
         flags = (K.CONV_MASK_IN if mask_in else 0) | (K.CONV_MASK_OUT if mask_out else 0)
         rd = None if res is None else res.detach().to(dtype).contiguous()
         y = K.conv1d_cl_raw(xd, R.fwd, None if bias is None else bias.detach().float(), res=rd, lengths=lengths, dil=dil, pad=pad,
-                            stride=stride, in_slope=in_slope, flags=flags, out_slope=out_slope)
+                            stride=stride, in_slope=in_slope, flags=flags, out_slope=out_slope, groups=groups)
+        ctx.groups = groups
         ctx.save_for_backward(xd, y if out_slope is not None else xd)
         ctx.R, ctx.out_slope = R, out_slope
         ctx.lengths, ctx.cfg, ctx.has_bias, ctx.x_dtype = lengths, (dil, pad, in_slope, mask_in, mask_out, stride), bias is not None, x.dtype
@@ -76,7 +77,7 @@ class ConvCLFn(torch.autograd.Function):
             if want_db and dy.size(2) % 8 == 0:
                 db = torch.empty(dy.size(2), dtype=torch.float32, device=dy.device)
             dw = K.conv1d_cl_wgrad_raw(xd, dy, k, lengths=ctx.lengths, dil=dil, pad=pad, stride=stride, in_slope=in_slope,
-                                       flags=K.CONV_MASK_IN if mask_in else 0, out=R.dw, dbias=db)
+                                       flags=K.CONV_MASK_IN if mask_in else 0, out=R.dw, dbias=db, groups=ctx.groups)
         if want_db and db is None:
             db = dy.sum((0, 1), dtype=torch.float32)
         dx = None
@@ -85,18 +86,18 @@ class ConvCLFn(torch.autograd.Function):
             # stride > 1: the kernel walks dY on the input's time grid phase by phase (in_div), no zero-insertion
             dx = K.conv1d_cl_raw(dy, WA.bwd_operand(R), None, mg_src=xs if in_slope != 1.0 else None, lengths=ctx.lengths, dil=dil,
                                  pad=dil * (k - 1) - pad, mg_slope=in_slope, flags=K.CONV_MASK_OUT if mask_in else 0,
-                                 in_div=stride, t_out=xd.size(1) if stride != 1 else None)
+                                 in_div=stride, t_out=xd.size(1) if stride != 1 else None, groups=ctx.groups)
             if dx.dtype != ctx.x_dtype:
                 dx = dx.to(ctx.x_dtype)
         dres = None
         if ctx.res_dtype is not None and ctx.needs_input_grad[10]:
             dres = dy if dy.dtype == ctx.res_dtype else dy.to(ctx.res_dtype)
-        return None, dx, dw, db, None, None, None, None, None, None, dres, None, None
+        return None, dx, dw, db, None, None, None, None, None, None, dres, None, None, None
 
 
 def conv_cl(x, w, bias=None, lengths=None, dil=1, pad=0, in_slope=1.0, mask_in=False, mask_out=False, dtype=None, res=None, stride=1,
-            out_slope=None):
-    return ConvCLFn.apply(dtype or compute_dtype(), x, w, bias, lengths, dil, pad, in_slope, mask_in, mask_out, res, stride, out_slope)
+            out_slope=None, groups=1):
+    return ConvCLFn.apply(dtype or compute_dtype(), x, w, bias, lengths, dil, pad, in_slope, mask_in, mask_out, res, stride, out_slope, groups)
 
 
 def weight_of(module, part=None, pad_in=0, pad_out=0):

@@ -6,7 +6,8 @@ import torch.nn.functional as F
 
 
 def conv1d_cl_raw(x, w, bias=None, bias_b=None, res=None, mg_src=None, out=None, lengths=None, dil=1, pad=0, stride=1,
-                  in_slope=1.0, mg_slope=1.0, out_scale=1.0, flags=0, gate_h=0, out2=None, out_slope=None, in_div=1, t_out=None):
+                  in_slope=1.0, mg_slope=1.0, out_scale=1.0, flags=0, gate_h=0, out2=None, out_slope=None, in_div=1, t_out=None, groups=1):
+    # groups: the operand is the dense block-diagonal weight, so the dense convolution below is exact
     b, t, c_in = x.shape
     if w.dim() == 4:                       # batched product: one [c_out][c_in] operand per item
         assert w.size(0) == b and w.size(1) == 1
@@ -80,7 +81,7 @@ def conv1d_cl_raw(x, w, bias=None, bias_b=None, res=None, mg_src=None, out=None,
     return v
 
 
-def conv1d_cl_wgrad_raw(x, dy, k, lengths=None, dil=1, pad=0, stride=1, in_slope=1.0, flags=0, out=None, dbias=None):
+def conv1d_cl_wgrad_raw(x, dy, k, lengths=None, dil=1, pad=0, stride=1, in_slope=1.0, flags=0, out=None, dbias=None, groups=1):
     b, t, c_in = x.shape
     c_out = dy.shape[2]
     w = torch.zeros(k, c_out, c_in, device=x.device, requires_grad=True)
@@ -94,6 +95,10 @@ def conv1d_cl_wgrad_raw(x, dy, k, lengths=None, dil=1, pad=0, stride=1, in_slope
     with torch.enable_grad():
         y = F.conv1d(xf.transpose(1, 2), w.permute(1, 2, 0), None, stride, pad, dil).transpose(1, 2)
         (g,) = torch.autograd.grad(y, w, dyf)
+    if groups > 1:                                   # compact [k][c_out][c_in/groups]: the diagonal blocks
+        og, ig = c_out // groups, c_in // groups
+        idx = (torch.arange(c_out, device=x.device) // og)[:, None] * ig + torch.arange(ig, device=x.device)[None, :]
+        g = torch.gather(g, 2, idx[None].expand(k, -1, -1))
     if dbias is not None:
         if flags & 8:
             dbias.add_(dyf.sum((0, 1)))
@@ -147,6 +152,14 @@ def weight_prep(arena):
             f.copy_(v.to(f.dtype))
             continue
         v = v.reshape(v.shape[:3])                          # Conv2d (k, 1) weights are read as [c_out][c_in][k]
+        if getattr(s, "groups", 1) > 1:                     # grouped -> dense block-diagonal
+            og, ig = s.c_out // s.groups, s.c_in // s.groups
+            dense = torch.zeros(s.c_out, s.c_in, s.k, device=v.device)
+            for gi in range(s.groups):
+                dense[gi * og:(gi + 1) * og, gi * ig:(gi + 1) * ig] = v[gi * og:(gi + 1) * og]
+            w = dense.permute(2, 0, 1)
+            f.copy_(w.to(f.dtype)); bw.copy_(w.flip(0).transpose(1, 2).to(bw.dtype))
+            continue
         if s.transpose:                                   # [c_in][c_out][k] -> [1][k*c_out][c_in_p]
             w = v.permute(2, 1, 0).reshape(1, s.k * s.c_out, s.c_in)
             f.zero_(); f[:, :, : s.c_in] = w.to(f.dtype)
@@ -167,6 +180,9 @@ def weight_prep_bwd(arena):
         if getattr(s, "torch_layout", False):
             dw = dwv.reshape(v.shape)
             rows = slice(0, v.shape[0])
+        elif getattr(s, "groups", 1) > 1:                   # compact [k][c_out][ig] -> [c_out][ig][k]
+            dw = dwv.permute(1, 2, 0)
+            rows = slice(0, s.c_out)
         elif s.transpose:
             dw = dwv[0, :, : s.c_in].reshape(s.k, s.c_out, s.c_in).permute(2, 1, 0)      # [c_in][c_out][k]
             rows = slice(0, s.c_in)

@@ -226,3 +226,39 @@ def test_flat_row_kernel_and_strided_data_gradient(pkg, dtype, tol):
             ga = K.conv1d_cl_wgrad_raw(x, dy, kk, lengths=lens, pad=pd, stride=st, in_slope=0.1, flags=fl | K.CONV_FLAT, dbias=dba)
             gb = cl_emul.conv1d_cl_wgrad_raw(x, dy, kk, lengths=lens, pad=pd, stride=st, in_slope=0.1, flags=fl, dbias=dbb)
             assert rel(ga, gb) < tol and rel(dba, dbb) < tol, ("wgrad", b, t, ci, co, kk, st)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-5), (torch.bfloat16, 1.5e-2)])
+def test_grouped_convolution_on_dense_operands(pkg, dtype, tol):
+    """DiscriminatorS' grouped layers (reference models.py:343-349): dense block-diagonal operands, the kernel walks only
+    the input channels a tile of output channels can see; forward, strided data gradient, compact weight gradient."""
+    import cl_emul
+    K = pkg.kernels
+    torch.manual_seed(9)
+    for (b, t, ci, co, groups, kk, st, pd) in [(3, 700, 16, 64, 4, 41, 4, 20), (3, 300, 64, 256, 16, 41, 4, 20),
+                                               (2, 200, 256, 1024, 64, 41, 4, 20), (4, 90, 1024, 1024, 256, 41, 4, 20)]:
+        ig, og = ci // groups, co // groups
+        wg = torch.randn(co, ig, kk, device=DEV) / (ig * kk) ** 0.5                 # torch grouped layout
+        dense = torch.zeros(co, ci, kk, device=DEV)
+        for g in range(groups):
+            dense[g * og:(g + 1) * og, g * ig:(g + 1) * ig] = wg[g * og:(g + 1) * og]
+        w = dense.permute(2, 0, 1).contiguous().to(dtype)
+        x = torch.randn(b, t, ci, device=DEV).to(dtype)
+        bias = torch.randn(co, device=DEV)
+        ya = K.conv1d_cl_raw(x, w, bias, pad=pd, stride=st, out_slope=0.1, groups=groups)
+        yr = torch.nn.functional.leaky_relu(torch.nn.functional.conv1d(x.float().transpose(1, 2), wg.to(dtype).float(), bias, st, pd, 1, groups), 0.1).transpose(1, 2)
+        assert ya.shape == yr.shape and rel(ya, yr) < tol, ("fwd", ci, co, groups)
+        dy = torch.randn_like(ya)
+        wb = w.flip(0).transpose(1, 2).contiguous()
+        xf = x.float().requires_grad_(True)
+        wf = wg.to(dtype).float().requires_grad_(True)
+        yq = torch.nn.functional.conv1d(xf.transpose(1, 2), wf, None, st, pd, 1, groups).transpose(1, 2)
+        dx_ref, dw_ref = torch.autograd.grad(yq, (xf, wf), dy.float())
+        dxa = K.conv1d_cl_raw(dy, wb, pad=kk - 1 - pd, in_div=st, t_out=t, groups=groups)
+        assert rel(dxa, dx_ref) < tol, ("dgrad", ci, co, groups)
+        db = torch.empty(co, device=DEV)
+        ga = K.conv1d_cl_wgrad_raw(x, dy, kk, pad=pd, stride=st, dbias=db, groups=groups)          # [k][co][ig]
+        assert ga.shape == (kk, co, ig) and rel(ga, dw_ref.permute(2, 0, 1)) < tol, ("wgrad", ci, co, groups)
+        assert rel(db, dy.float().sum((0, 1))) < tol
+        ge = cl_emul.conv1d_cl_wgrad_raw(x, dy, kk, pad=pd, stride=st, groups=groups)
+        assert rel(ge, dw_ref.permute(2, 0, 1)) < tol

@@ -56,3 +56,30 @@ def test_mpd_through_arena(emulated, monkeypatch, hip_p):
     (sum(g.pow(2).mean() for g in go) + sum(f.abs().mean() for fm in fgo for f in fm)).backward()
     for k, p in d.named_parameters():
         assert rel_err(p.grad, sd[k].grad) < 5e-5, k
+
+
+@pytest.mark.parametrize("in_scope", [False, True])
+def test_discriminator_s_channels_last(emulated, in_scope):
+    """DiscriminatorS on the channels-last kernels (grouped layers as dense block-diagonal operands, compact weight
+    gradients) against the oracle: logits, feature maps and every parameter gradient."""
+    pkg = emulated
+    import importlib
+    WA = importlib.import_module("personalized_text-to-speech_amd.weight_arena")
+    torch.manual_seed(3)
+    mpd = pkg.MultiPeriodDiscriminator(False)
+    d = mpd.discriminators[0]
+    sd = {"d." + k: v.detach().clone().requires_grad_(True) for k, v in d.state_dict().items()}
+    x = torch.rand(2, 1, 1200) * 2 - 1
+    if in_scope:
+        with WA.scope(mpd, type(mpd)._arena_specs):
+            la, fa = d.forward_hip(x)
+    else:
+        la, fa = d.forward_hip(x)
+    lo, fo = O.disc_s(sd, "d", x)
+    assert rel_err(la, lo) < 1e-5
+    for a, b in zip(fa, fo):
+        assert a.shape == b.shape and rel_err(a, b) < 1e-5
+    (la.pow(2).mean() + sum(f.abs().mean() for f in fa)).backward()
+    (lo.pow(2).mean() + sum(f.abs().mean() for f in fo)).backward()
+    for k, p in d.named_parameters():
+        assert rel_err(p.grad, sd["d." + k].grad) < 5e-5, k

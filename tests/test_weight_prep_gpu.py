@@ -35,3 +35,29 @@ def test_prep_forward_and_backward(pkg, dtype, tol):
     got = arena.dparam.clone()
     cl_emul.weight_prep_bwd(arena)
     assert rel(got, arena.dparam) < 2e-5
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.bfloat16, 1e-2)])
+def test_prep_discriminator_arena_with_grouped_layers(pkg, dtype, tol):
+    """The discriminators' arena: Conv2d (k,1) weights, padded first/last layers and DiscriminatorS' grouped layers
+    (layout 3: dense block-diagonal operands, compact weight gradient)."""
+    WA = importlib.import_module("personalized_text-to-speech_amd.weight_arena")
+    torch.manual_seed(5)
+    mpd = pkg.MultiPeriodDiscriminator(False).cuda()
+    mpd.discriminators = torch.nn.ModuleList(list(mpd.discriminators)[:2])          # S and one P: every layout, less memory
+    arena = WA.WeightArena(type(mpd)._arena_specs(mpd), dtype)
+    assert any(s.groups > 1 for s in arena.specs)
+    arena.prepare()
+    torch.cuda.synchronize()
+    got_f, got_b = arena.w_fwd.clone(), arena.w_bwd.clone()
+    cl_emul.weight_prep(arena)
+    rel = lambda a, b: float((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-12))
+    assert rel(got_f, arena.w_fwd) < tol and rel(got_b, arena.w_bwd) < tol
+    arena.dw.normal_()
+    rc = pkg._lib.lib().vits_weight_prep_bwd(arena.table.data_ptr(), arena.n, arena.total_rows, arena.dw.data_ptr(),
+                                             arena.dparam.data_ptr(), pkg._lib.stream_ptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    got = arena.dparam.clone()
+    cl_emul.weight_prep_bwd(arena)
+    assert rel(got, arena.dparam) < 2e-5

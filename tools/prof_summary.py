@@ -38,7 +38,7 @@ def main():
     print(f"# steady-state window: {a.steps} steps, wall {wall/1e6:.3f} ms/step, kernel-busy {busy/1e6:.3f} ms/step, "
           f"{len(win)/a.steps:.0f} launches/step, {len(agg)} distinct kernels")
     cats = collections.OrderedDict([
-        ("hip: this repo's kernels", ("conv1d_cl", "wgrad_kernel", "reduce_slabs", "reduce_partials", "fold_kernel", "unfold_kernel", "mas_kernel", "ln_act", "dwconv", "spline_kernel", "prep_fwd", "prep_bwd", "vits_")),
+        ("hip: this repo's kernels", ("conv1d_cl", "conv1d_flat", "relsoftmax", "rq_spline", "wgrad_kernel", "reduce_slabs", "reduce_partials", "fold_kernel", "unfold_kernel", "mas_kernel", "ln_act", "dwconv", "spline_kernel", "prep_fwd", "prep_bwd", "vits_")),
         ("MIOpen convolution (+layout/im2col helpers)", ("igemm_", "naive_conv", "ck::", "_ZN2ck", "Im2d2Col", "Col2Im", "batched_transpose", "SubTensorOp", "miopen", "Im3d", "gridwise")),
         ("rocBLAS/hipBLASLt GEMM", ("Cijk_",)),
         ("aten elementwise/copy/cast", ("elementwise_kernel", "vectorized_elementwise", "CatArrayBatchedCopy", "index", "fill", "copy")),
