@@ -17,15 +17,16 @@ from . import _lib
 from . import monotonic_align as _ma
 
 BACKENDS = {
-    "maximum_path (alignment DP)": "hip",
-    "decoder (Generator: conv_pre, ups, ResBlocks, conv_post; fwd+bwd)": "hip",
-    "posterior encoder + flow (1x1 pre/post/proj, gated WN stacks; fwd+bwd)": "hip",
-    "stochastic duration predictor (DDSConv: dwconv, LayerNorm+GELU, 1x1; spline; fwd+bwd)": "hip",
-    "weight preparation (weight-norm, layouts, dtype; fwd+bwd)": "hip",
-    "text encoder (relative-position attention products + softmax row kernels, FFN, LayerNorm; fwd+bwd)": "hip",
-    "stft (framed windowed DFT as an exact-fp32 MFMA product; fwd+bwd)": "hip",
-    "discriminators (MIOpen, as BASELINE.json allows; HIP path for the period discriminators exists, off by default)": "rocm",
-    "AdamW (torch fused multi-tensor)": "rocm",
+    "maximum_path": "hip",                # csrc/mas.hip (vits_mas_f32)
+    "conv1d (channels-last, fused epilogues: generator, text encoder, STFT/mel, discriminators)": "hip",   # conv1d_cl.hip, conv1d_flat.hip
+    "conv1d weight+bias gradient": "hip",  # conv1d_cl_wgrad.hip
+    "conv_transpose1d": "hip",            # 1x1 product on conv1d_cl + convt_fold.hip
+    "weight_norm (+autograd), operand layouts": "hip",   # weight_prep.hip, one launch per network
+    "layer_norm+gelu, depthwise conv": "hip",             # rowops.hip
+    "relative-position attention": "hip",  # attn_softmax.hip + batched products on conv1d_cl
+    "rational_quadratic_spline (+autograd)": "hip",       # rq_spline.hip
+    "element-wise glue, losses, embeddings, mel matmul": "rocm",   # PyTorch-ROCm device ops
+    "adamw": "rocm",                      # torch.optim.AdamW(fused=True, capturable=True)
 }
 
 
