@@ -277,6 +277,23 @@ int vits_relsoftmax_bwd(int dtype, const void* p, const void* dpd, const void* d
                         const int32_t* lengths, void* ds, void* dsband, int b, int t, int ld, int window, float scale,
                         void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Deterministic two-stage reductions for the loss terms (csrc/reduce.hip).  No zero-initialised memory, no atomics:
+ * stage 1 writes one partial per workgroup into `workspace` (>= vits_reduce_workspace(n_seg) bytes), stage 2 sums them in
+ * a fixed order.
+ *   vits_absdiff_sum   out[0] (+)= scale * sum_i |a[i] - b[i]|   — one term of feature_loss (reference losses.py:7-15:
+ *                      mean |rl - gl| over a feature map; a = real half, b = generated half of one channels-last tensor)
+ *   vits_absdiff_bwd   db[i] = -sign(a[i]-b[i]) * scale * g[0];  da (optional) = 0  (the reference detaches the real half)
+ *   vits_segsum_f32    out[s] = sum_i x[s*seg_len + i]            — torch.sum(x, [1,2]) of the duration predictor
+ *                      (models.py:71-102) and whole-tensor sums (n_seg = 1: kl_loss, losses.py:46-61)
+ * ------------------------------------------------------------------------------------------ */
+size_t vits_reduce_workspace(int n_seg);
+int vits_absdiff_sum(int dtype, const void* a, const void* b, size_t n, float scale, float* out, int accumulate,
+                     void* workspace, size_t workspace_bytes, void* stream);
+int vits_absdiff_bwd(int dtype, const void* a, const void* b, size_t n, const float* g, float scale, void* da, void* db,
+                     void* stream);
+int vits_segsum_f32(const float* x, int n_seg, size_t seg_len, float* out, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,131 @@
+// Deterministic two-stage reductions for the loss terms of the fine-tune step (reference losses.py:7-61 and the
+// [1,2]-sums of the duration predictor, models.py:71-102).
+//
+// Why not torch.sum / torch.mean: their multi-block path zeroes a semaphore with hipMemsetAsync before every launch, and
+// device memset nodes are the one node type the captured step cannot rely on.  These kernels need no
+// zero-initialised memory: stage 1 writes one partial per workgroup, stage 2 sums the partials in a fixed order.
+//   vits_absdiff_sum   out (+)= scale * sum |a - b|           (feature-matching loss: a = real half, b = generated half)
+//   vits_absdiff_bwd   db = -sign(a - b) * scale * g,  da = 0 (the reference detaches the real half, losses.py:11)
+//   vits_segsum_f32    out[s] = sum x[s][:]                    (per-item sums, whole-tensor sums with n_seg = 1)
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxSplits = 256;
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+  return s;
+}
+
+template <typename T> __device__ __forceinline__ float ld(const T* p, size_t i);
+template <> __device__ __forceinline__ float ld<float>(const float* p, size_t i) { return p[i]; }
+template <> __device__ __forceinline__ float ld<__bf16>(const __bf16* p, size_t i) { return (float)p[i]; }
+
+// stage 1: partial[seg][split] = sum over the split's strided slice of f(seg, i)
+template <typename T, bool ABSDIFF>
+__global__ __launch_bounds__(kThreads) void partial_kernel(const T* __restrict__ a, const T* __restrict__ b, size_t seg_len,
+                                                          float* __restrict__ partial) {
+  __shared__ float red[4];
+  const size_t base = (size_t)blockIdx.y * seg_len;
+  float acc = 0.f;
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < seg_len; i += (size_t)gridDim.x * kThreads) {
+    const float x = ld<T>(a, base + i);
+    acc += ABSDIFF ? fabsf(x - ld<T>(b, base + i)) : x;
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = acc;
+}
+
+// stage 2: out[seg] (+)= scale * sum_s partial[seg][s]   (one wave per segment, fixed order)
+__global__ __launch_bounds__(64) void final_kernel(const float* __restrict__ partial, int splits, float scale, float* __restrict__ out,
+                                                   int accumulate) {
+  const int seg = blockIdx.x;
+  float acc = 0.f;
+  for (int s = threadIdx.x; s < splits; s += 64) acc += partial[(size_t)seg * splits + s];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (threadIdx.x == 0) out[seg] = (accumulate ? out[seg] : 0.f) + scale * acc;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void absdiff_bwd_kernel(const T* __restrict__ a, const T* __restrict__ b, size_t n,
+                                                              const float* __restrict__ g, float scale, T* __restrict__ da,
+                                                              T* __restrict__ db) {
+  const float gs = g[0] * scale;
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (size_t)gridDim.x * kThreads) {
+    const float d = ld<T>(a, i) - ld<T>(b, i);
+    const float v = d > 0.f ? -gs : (d < 0.f ? gs : 0.f);          // d|a-b|/db = -sign(a-b)
+    db[i] = (T)v;
+    if (da) da[i] = (T)0.f;
+  }
+}
+
+int pick_splits(size_t seg_len, int n_seg) {
+  long s = (long)((seg_len + (size_t)kThreads * 8 - 1) / ((size_t)kThreads * 8));     // >= 8 elements per thread
+  const long fill = (1024 + n_seg - 1) / n_seg;                                      // ~4 workgroups per CU in total
+  if (s > fill) s = fill;
+  if (s > kMaxSplits) s = kMaxSplits;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
+}  // namespace
+
+extern "C" size_t vits_reduce_workspace(int n_seg) { return (size_t)n_seg * kMaxSplits * sizeof(float); }
+
+extern "C" int vits_absdiff_sum(int dtype, const void* a, const void* b, size_t n, float scale, float* out, int accumulate,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  if (!a || !b || !out || !workspace || n == 0) return VITS_E_BADARG;
+  if (workspace_bytes < vits_reduce_workspace(1)) return VITS_E_BADARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int splits = pick_splits(n, 1);
+  float* part = static_cast<float*>(workspace);
+  if (dtype == VITS_DT_BF16)
+    hipLaunchKernelGGL((partial_kernel<__bf16, true>), dim3(splits, 1), dim3(kThreads), 0, s, static_cast<const __bf16*>(a),
+                       static_cast<const __bf16*>(b), n, part);
+  else if (dtype == VITS_DT_F32)
+    hipLaunchKernelGGL((partial_kernel<float, true>), dim3(splits, 1), dim3(kThreads), 0, s, static_cast<const float*>(a),
+                       static_cast<const float*>(b), n, part);
+  else
+    return VITS_E_UNSUPPORTED;
+  hipLaunchKernelGGL(final_kernel, dim3(1), dim3(64), 0, s, part, splits, scale, out, accumulate);
+  return vits::check_launch("vits_absdiff_sum");
+}
+
+extern "C" int vits_absdiff_bwd(int dtype, const void* a, const void* b, size_t n, const float* g, float scale, void* da, void* db,
+                                void* stream) {
+  if (!a || !b || !g || !db || n == 0) return VITS_E_BADARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  size_t blocks = (n + (size_t)kThreads * 8 - 1) / ((size_t)kThreads * 8);
+  if (blocks > 2048) blocks = 2048;
+  if (dtype == VITS_DT_BF16)
+    hipLaunchKernelGGL(absdiff_bwd_kernel<__bf16>, dim3((unsigned)blocks), dim3(kThreads), 0, s, static_cast<const __bf16*>(a),
+                       static_cast<const __bf16*>(b), n, g, scale, static_cast<__bf16*>(da), static_cast<__bf16*>(db));
+  else if (dtype == VITS_DT_F32)
+    hipLaunchKernelGGL(absdiff_bwd_kernel<float>, dim3((unsigned)blocks), dim3(kThreads), 0, s, static_cast<const float*>(a),
+                       static_cast<const float*>(b), n, g, scale, static_cast<float*>(da), static_cast<float*>(db));
+  else
+    return VITS_E_UNSUPPORTED;
+  return vits::check_launch("vits_absdiff_bwd");
+}
+
+extern "C" int vits_segsum_f32(const float* x, int n_seg, size_t seg_len, float* out, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+  if (!x || !out || !workspace || n_seg <= 0 || seg_len == 0) return VITS_E_BADARG;
+  if (workspace_bytes < vits_reduce_workspace(n_seg)) return VITS_E_BADARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int splits = pick_splits(seg_len, n_seg);
+  float* part = static_cast<float*>(workspace);
+  hipLaunchKernelGGL((partial_kernel<float, false>), dim3(splits, n_seg), dim3(kThreads), 0, s, x, x, seg_len, part);
+  hipLaunchKernelGGL(final_kernel, dim3(n_seg), dim3(64), 0, s, part, splits, 1.0f, out, 0);
+  return vits::check_launch("vits_segsum_f32");
+}
