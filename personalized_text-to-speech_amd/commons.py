@@ -101,3 +101,12 @@ def kl_divergence(m_p, logs_p, m_q, logs_q):
 
 
 LOG_2PI = math.log(2 * math.pi)
+
+
+def sum12(x):
+    """torch.sum(x, [1, 2]) — on the GPU through this library's deterministic two-stage reduction (reduce.py: torch's
+    multi-block path depends on a device memset, which a replayed hipGraph cannot rely on)."""
+    if x.is_cuda:
+        from . import reduce
+        return reduce.sum12(x)
+    return torch.sum(x, [1, 2])

@@ -5,6 +5,10 @@ import torch
 
 
 def feature_loss(fmap_r, fmap_g):
+    cl = getattr(fmap_g, "cl", None)
+    if cl is not None and getattr(fmap_r, "cl", None) is cl and cl[0][0].is_cuda:
+        from . import reduce                      # both lists come from one MultiPeriodDiscriminator call: fused kernel path
+        return reduce.feature_l1(*cl)
     loss = 0
     for dr, dg in zip(fmap_r, fmap_g):
         for rl, gl in zip(dr, dg):
@@ -39,4 +43,7 @@ def kl_loss(z_p, logs_q, m_p, logs_p, z_mask):
     z_p, logs_q, m_p, logs_p, z_mask = (t.float() for t in (z_p, logs_q, m_p, logs_p, z_mask))
     kl = logs_p - logs_q - 0.5
     kl = kl + 0.5 * ((z_p - m_p) ** 2) * torch.exp(-2.0 * logs_p)
+    if kl.is_cuda:
+        from . import reduce
+        return reduce.sum_all(kl * z_mask) / reduce.sum_all(z_mask)
     return torch.sum(kl * z_mask) / torch.sum(z_mask)

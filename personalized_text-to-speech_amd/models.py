@@ -68,7 +68,7 @@ class StochasticDurationPredictor(nn.Module):
             if isinstance(flow, modules.ElementwiseAffine):
                 mm, ls = flow.m.view(1, 1, -1), flow.logs.view(1, 1, -1)
                 if not reverse:
-                    return (mm + torch.exp(ls) * z) * m, torch.sum(ls * m, [1, 2])
+                    return (mm + torch.exp(ls) * z) * m, commons.sum12(ls * m)
                 return (z - mm) * torch.exp(-ls) * m, None
             out = flow.forward_cl(z, lengths, m, cond, reverse)
             return (out[0], out[1]) if not reverse else (out, None)
@@ -89,17 +89,17 @@ class StochasticDurationPredictor(nn.Module):
             z_u, z1 = z_q[..., :1], z_q[..., 1:]
             u = torch.sigmoid(z_u) * m
             z0 = (w_cl - u) * m
-            logdet_tot_q = logdet_tot_q + torch.sum((F.logsigmoid(z_u) + F.logsigmoid(-z_u)) * m, [1, 2])
-            logq = torch.sum(-0.5 * (commons.LOG_2PI + (e_q ** 2)) * m, [1, 2]) - logdet_tot_q
+            logdet_tot_q = logdet_tot_q + commons.sum12((F.logsigmoid(z_u) + F.logsigmoid(-z_u)) * m)
+            logq = commons.sum12(-0.5 * (commons.LOG_2PI + (e_q ** 2)) * m) - logdet_tot_q
 
             z0 = torch.log(torch.clamp_min(z0, 1e-5)) * m             # modules.Log
-            logdet_tot = torch.sum(-z0, [1, 2])
+            logdet_tot = commons.sum12(-z0)
             z = torch.cat([z0, z1], -1)
             for flow in self.flows:
                 z, ld = run(flow, z, xc)
                 if ld is not None:
                     logdet_tot = logdet_tot + ld
-            nll = torch.sum(0.5 * (commons.LOG_2PI + (z ** 2)) * m, [1, 2]) - logdet_tot
+            nll = commons.sum12(0.5 * (commons.LOG_2PI + (z ** 2)) * m) - logdet_tot
             return nll + logq                                          # [b]
         flows = list(reversed(self.flows))
         flows = flows[:-2] + [flows[-1]]                              # models.py:88-89 "remove a useless vflow"
@@ -294,6 +294,15 @@ class _WNConv2dK1(nn.Module):
         return F.conv2d(x, w.to(x.dtype), self.bias.to(x.dtype), self.stride, self.padding)
 
 
+class _Fmaps(list):
+    """Feature maps in the reference's layout (views) + the contiguous channels-last tensors they view (`cl`, items of the
+    real half of the batch first) and the element count of one half of each feature map (`den`): reduce.feature_l1."""
+
+    def __init__(self):
+        super().__init__()
+        self.cl, self.den = [], []
+
+
 class DiscriminatorP(nn.Module):
     # models.py:299-335
     def __init__(self, period, kernel_size=5, stride=3, use_spectral_norm=False):
@@ -338,7 +347,7 @@ class DiscriminatorP(nn.Module):
         layers run as strided channels-last 1-D convolutions on the MFMA kernel, leaky-relu fused as epilogue."""
         from . import wn_cl
         dtype = wn_cl.compute_dtype()
-        fmap = []
+        fmap = _Fmaps()
         n, c, t = x.shape
         p_ = self.period
         if t % p_ != 0:                                             # pad first (models.py:319-322)
@@ -352,10 +361,13 @@ class DiscriminatorP(nn.Module):
             w = wn_cl.weight_of(l, pad_in=7 if i == 0 else 0)
             h = wn_cl.conv_cl(h, w, l.bias, pad=l.padding[0], stride=l.stride[0], out_slope=modules.LRELU_SLOPE, dtype=dtype)
             fmap.append(h.view(n, p_, h.size(1), h.size(2)).permute(0, 3, 2, 1))          # [n, c, t', period] view
+            fmap.cl.append(h); fmap.den.append(h.numel() // 2)
         l = self.conv_post
-        y = wn_cl.conv_cl(h, wn_cl.weight_of(l, pad_out=7), wn_cl.bias_of(l, 7), pad=l.padding[0], dtype=dtype)[..., :1]
+        y8 = wn_cl.conv_cl(h, wn_cl.weight_of(l, pad_out=7), wn_cl.bias_of(l, 7), pad=l.padding[0], dtype=dtype)
+        y = y8[..., :1]                                                                   # channels 1..7 are exactly zero
         y = y.reshape(n, p_, y.size(1), 1).permute(0, 3, 2, 1)                            # [n, 1, t'', period]
         fmap.append(y)
+        fmap.cl.append(y8); fmap.den.append(y.numel() // 2)
         return torch.flatten(y, 1, -1), fmap
 
 
@@ -405,7 +417,7 @@ class DiscriminatorS(nn.Module):
         kernel only walks the input channels a tile of output channels can see (vits_conv_desc.groups)."""
         from . import wn_cl, weight_arena as WA
         dtype = wn_cl.compute_dtype()
-        fmap = []
+        fmap = _Fmaps()
         h = F.pad(x.transpose(1, 2), (0, 7)).to(dtype)                   # [n, t, 1] -> c_in 8 (vector width), zero weights there
         for i, l in enumerate(self.convs):
             groups = l.groups
@@ -414,10 +426,12 @@ class DiscriminatorS(nn.Module):
                 w, groups = _dense_grouped_weight(l, 7 if i == 0 else 0), 1
             h = wn_cl.conv_cl(h, w, l.bias, pad=l.padding, stride=l.stride, out_slope=modules.LRELU_SLOPE, dtype=dtype, groups=groups)
             fmap.append(h.transpose(1, 2))
+            fmap.cl.append(h); fmap.den.append(h.numel() // 2)
         l = self.conv_post
-        y = wn_cl.conv_cl(h, wn_cl.weight_of(l, pad_out=7), wn_cl.bias_of(l, 7), pad=l.padding, dtype=dtype)[..., :1]
-        y = y.transpose(1, 2)
+        y8 = wn_cl.conv_cl(h, wn_cl.weight_of(l, pad_out=7), wn_cl.bias_of(l, 7), pad=l.padding, dtype=dtype)
+        y = y8[..., :1].transpose(1, 2)                                  # channels 1..7 are exactly zero
         fmap.append(y)
+        fmap.cl.append(y8); fmap.den.append(y.numel() // 2)
         return torch.flatten(y, 1, -1), fmap
 
 
@@ -440,9 +454,15 @@ class MultiPeriodDiscriminator(nn.Module):
         y_d_rs, y_d_gs, fmap_rs, fmap_gs = [], [], [], []
         with weight_arena.scope(self, MultiPeriodDiscriminator._arena_specs):
             outs = [d(yy) for d in self.discriminators]
+        from .reduce import FmapLists
+        fmap_rs, fmap_gs = FmapLists(), FmapLists()
+        cl, den = [], []
         for out, fmap in outs:
             y_d_rs.append(out[:b]); y_d_gs.append(out[b:])
             fmap_rs.append([f[:b] for f in fmap]); fmap_gs.append([f[b:] for f in fmap])
+            cl += getattr(fmap, "cl", [None] * len(fmap)); den += getattr(fmap, "den", [0] * len(fmap))
+        if all(h is not None for h in cl):            # every discriminator ran channels-last: the fused feature loss applies
+            fmap_rs.cl = fmap_gs.cl = (cl, den)
         return y_d_rs, y_d_gs, fmap_rs, fmap_gs
 
     @staticmethod
@@ -580,7 +600,7 @@ class SynthesizerTrn(nn.Module):
         else:
             logw_ = torch.log(w + 1e-6) * x_mask
             logw = self.dp(x, x_mask, g=g)
-            l_length = torch.sum((logw - logw_) ** 2, [1, 2]) / torch.sum(x_mask)
+            l_length = commons.sum12((logw - logw_) ** 2) / torch.sum(x_mask)
 
         # expand prior
         m_p = torch.matmul(attn.squeeze(1), m_p.transpose(1, 2)).transpose(1, 2)
@@ -599,7 +619,7 @@ class SynthesizerTrn(nn.Module):
             logw = self.dp(x, x_mask, g=g)
         w = torch.exp(logw) * x_mask * length_scale
         w_ceil = torch.ceil(w)
-        y_lengths = torch.clamp_min(torch.sum(w_ceil, [1, 2]), 1).long()
+        y_lengths = torch.clamp_min(commons.sum12(w_ceil), 1).long()
         y_mask = torch.unsqueeze(commons.sequence_mask(y_lengths, None), 1).to(x_mask.dtype)
         attn_mask = torch.unsqueeze(x_mask, 2) * torch.unsqueeze(y_mask, -1)
         attn = commons.generate_path(w_ceil, attn_mask)

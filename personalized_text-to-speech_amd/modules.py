@@ -234,7 +234,7 @@ class Log(nn.Module):
     def forward(self, x, x_mask, reverse=False, **kwargs):
         if not reverse:
             y = torch.log(torch.clamp_min(x, 1e-5)) * x_mask
-            return y, torch.sum(-y, [1, 2])
+            return y, commons.sum12(-y)
         return torch.exp(x) * x_mask
 
 
@@ -258,7 +258,7 @@ class ElementwiseAffine(nn.Module):
     def forward(self, x, x_mask, reverse=False, **kwargs):
         if not reverse:
             y = (self.m + torch.exp(self.logs) * x) * x_mask
-            return y, torch.sum(self.logs * x_mask, [1, 2])
+            return y, commons.sum12(self.logs * x_mask)
         return (x - self.m) * torch.exp(-self.logs) * x_mask
 
 
@@ -299,7 +299,7 @@ class ResidualCouplingLayer(nn.Module):
             m, logs = stats, None
         if not reverse:
             x1 = m + (x1 * torch.exp(logs) if logs is not None else x1) * mask_cl
-            logdet = torch.sum(logs, [1, 2]) if logs is not None else torch.zeros(x.size(0), dtype=x.dtype, device=x.device)
+            logdet = commons.sum12(logs) if logs is not None else torch.zeros(x.size(0), dtype=x.dtype, device=x.device)
             return torch.cat([x0, x1], -1), logdet
         x1 = (x1 - m) * (torch.exp(-logs) if logs is not None else 1.0) * mask_cl
         return torch.cat([x0, x1], -1)

@@ -1,0 +1,107 @@
+"""Loss-side reductions on this library's deterministic two-stage kernels (csrc/reduce.hip) instead of torch.sum /
+torch.mean: those zero a semaphore with a device memset before every multi-block launch, and memset nodes are what a
+replayed hipGraph cannot rely on.  Also fuses the feature-matching loss (reference losses.py:7-15).
+
+  sum12(x)            torch.sum(x, [1, 2]) for a float32 [b, ., .] tensor            (models.py:71-102, modules.py)
+  sum_all(x)          torch.sum(x) for a float32 tensor                                 (kl_loss, losses.py:46-61)
+  feature_l1(hs)      sum_l 2 * mean |real_l - generated_l| over channels-last feature maps whose first half of the
+                      batch is real and second half generated; gradient only to the generated half (losses.py:11)
+"""
+import torch
+
+from . import _lib
+from . import kernels as K
+
+_DT = {torch.float32: 0, torch.bfloat16: 2}
+
+
+def _ws(n_seg, device):
+    L = _lib.lib()
+    nbytes = L.vits_reduce_workspace(n_seg)
+    return K.workspace(nbytes, device), nbytes
+
+
+class _SegSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, n_seg):
+        xd = x.detach()
+        if xd.dtype != torch.float32 or not xd.is_contiguous():
+            xd = xd.float().contiguous()
+        _lib.require_cuda(xd)
+        out = torch.empty(n_seg, device=x.device, dtype=torch.float32)
+        ws, nbytes = _ws(n_seg, x.device)
+        rc = _lib.lib().vits_segsum_f32(xd.data_ptr(), n_seg, xd.numel() // n_seg, out.data_ptr(), ws.data_ptr(), nbytes, _lib.stream_ptr())
+        _lib.check(rc, "vits_segsum_f32")
+        ctx.shape, ctx.dtype, ctx.n_seg = x.shape, x.dtype, n_seg
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        shape = ctx.shape
+        gx = g.to(ctx.dtype).view([ctx.n_seg] + [1] * (len(shape) - 1)).expand(shape) if ctx.n_seg > 1 else g.to(ctx.dtype).expand(shape)
+        return gx, None
+
+
+def sum12(x):
+    """torch.sum(x, [1, 2]) -> [b]"""
+    assert x.dim() == 3
+    return _SegSum.apply(x, x.size(0))
+
+
+def sum_all(x):
+    """torch.sum(x) -> 0-d"""
+    return _SegSum.apply(x, 1).view(())
+
+
+class _FeatureL1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dens, *hs):
+        L = _lib.lib()
+        dev = hs[0].device
+        out = torch.empty(1, device=dev, dtype=torch.float32)
+        ws, nbytes = _ws(1, dev)
+        saved = []
+        for i, h in enumerate(hs):
+            hd = h.detach()
+            assert hd.is_contiguous() and hd.size(0) % 2 == 0 and hd.dtype in _DT
+            _lib.require_cuda(hd)
+            n = hd.numel() // 2
+            es = hd.element_size()
+            rc = L.vits_absdiff_sum(_DT[hd.dtype], hd.data_ptr(), hd.data_ptr() + n * es, n, 2.0 / dens[i], out.data_ptr(), 1 if i else 0,
+                                    ws.data_ptr(), nbytes, _lib.stream_ptr())
+            _lib.check(rc, "vits_absdiff_sum")
+            saved.append(hd)
+        ctx.save_for_backward(*saved)
+        ctx.dens = dens
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        gf = g.detach().float().contiguous().view(1)
+        grads = []
+        for i, hd in enumerate(ctx.saved_tensors):
+            if not ctx.needs_input_grad[i + 1]:
+                grads.append(None)
+                continue
+            n = hd.numel() // 2
+            es = hd.element_size()
+            dh = torch.empty_like(hd)
+            rc = L.vits_absdiff_bwd(_DT[hd.dtype], hd.data_ptr(), hd.data_ptr() + n * es, n, gf.data_ptr(), 2.0 / ctx.dens[i],
+                                    dh.data_ptr(), dh.data_ptr() + n * es, _lib.stream_ptr())
+            _lib.check(rc, "vits_absdiff_bwd")
+            grads.append(dh)
+        return (None, *grads)
+
+
+def feature_l1(hs, dens=None):
+    """dens[i]: number of elements of ONE half of feature map i (differs from hs[i].numel() / 2 when hs[i] carries
+    zero padding channels)."""
+    dens = tuple(int(d) for d in (dens or [h.numel() // 2 for h in hs]))
+    return _FeatureL1.apply(dens, *hs)
+
+
+class FmapLists(list):
+    """The list of per-discriminator feature-map lists MultiPeriodDiscriminator returns (reference layout views), carrying
+    the channels-last tensors they are views of (`cl`: real items first, generated items second) for the fused loss."""
+    cl = None
