@@ -532,11 +532,7 @@ class SynthesizerTrn(nn.Module):
             H, out = wn.hidden_channels, []
             for i in range(wn.n_layers):
                 out.append(Spec(wn.in_layers[i]))
-                rs = wn.res_skip_layers[i]
-                if i < wn.n_layers - 1:
-                    out += [Spec(rs, "res", 0, H), Spec(rs, "skip", H, H)]
-                else:
-                    out.append(Spec(rs, "skip"))
+                out.append(Spec(wn.res_skip_layers[i]))        # rows [0, H) residual, [H, 2H) skip: one operand, one gradient launch
             return out
 
         def dds_specs(dds):

@@ -125,19 +125,16 @@ class WNPlan:
 
 
 def wn_prepared_weights(wn):
-    """Per layer: w_in, b_in, w_res (None for the last layer), w_skip, b_rs."""
-    H, out = wn.hidden_channels, []
+    """Per layer: w_in, b_in, w_rs (res rows first, then skip rows; skip only for the last layer), b_rs."""
+    out = []
     for i in range(wn.n_layers):
         rs = wn.res_skip_layers[i]
         w_in = WA.handle_for(wn.in_layers[i])
         if w_in is not None:
-            w_res = WA.handle_for(rs, "res") if i < wn.n_layers - 1 else None
-            w_skip = WA.handle_for(rs, "skip")
+            w_rs = WA.handle_for(rs)
         else:
-            w_in = prep_conv(wn.in_layers[i].weight)
-            w_rs = prep_conv(rs.weight)
-            w_res, w_skip = (w_rs[:, :H].contiguous(), w_rs[:, H:].contiguous()) if i < wn.n_layers - 1 else (None, w_rs)
-        out += [w_in, wn.in_layers[i].bias, w_res, w_skip, rs.bias]
+            w_in, w_rs = prep_conv(wn.in_layers[i].weight), prep_conv(rs.weight)
+        out += [w_in, wn.in_layers[i].bias, w_rs, rs.bias]
     return out
 
 
@@ -163,18 +160,18 @@ class WNFn(torch.autograd.Function):
         out = torch.empty_like(h)
         saved = []
         for i in range(L):
-            r_in, b_in, r_res, r_skip, b_rs = R[5 * i], bias[5 * i + 1], R[5 * i + 2], R[5 * i + 3], bias[5 * i + 4]
+            r_in, b_in, r_rs, b_rs = R[4 * i], bias[4 * i + 1], R[4 * i + 2], bias[4 * i + 3]
             d = plan.dils[i]
             pre = torch.empty(h.size(0), h.size(1), 2 * H, device=h.device, dtype=dtype)
             acts = C(h, r_in.fwd, b_in, bias_b=None if cd is None else cd[i], dil=d, pad=(k * d - d) // 2,
                      flags=K.CONV_GATE, gate_h=H, out2=pre)
             acc = K.CONV_ACCUM if i > 0 else 0
-            if i < L - 1:
-                h_next = C(acts, r_res.fwd, b_rs[:H], res=h, lengths=lengths, flags=K.CONV_MASK_OUT)
-                C(acts, r_skip.fwd, b_rs[H:], out=out, lengths=lengths, flags=K.CONV_MASK_OUT | acc)
+            if i < L - 1:                                   # rows [0, H) of the res_skip operand feed the residual, [H, 2H) the skip sum
+                h_next = C(acts, r_rs.fwd[:, :H], b_rs[:H], res=h, lengths=lengths, flags=K.CONV_MASK_OUT)
+                C(acts, r_rs.fwd[:, H:], b_rs[H:], out=out, lengths=lengths, flags=K.CONV_MASK_OUT | acc)
             else:
                 h_next = None
-                C(acts, r_skip.fwd, b_rs, out=out, lengths=lengths, flags=K.CONV_MASK_OUT | acc)
+                C(acts, r_rs.fwd, b_rs, out=out, lengths=lengths, flags=K.CONV_MASK_OUT | acc)
             saved += [h, pre, acts]
             h = h_next
         ctx.plan, ctx.dtype, ctx.lengths, ctx.has_cond, ctx.R = plan, dtype, lengths, cd is not None, R
@@ -183,46 +180,41 @@ class WNFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_out):
+        """Per layer: ONE weight-gradient launch for the res_skip convolution (dy = [d_h | d_o], a [b,t,2H] buffer whose
+        left half is rewritten in place by each layer's data gradient), ONE data-gradient launch through it (reduction
+        over 2H channels, gate chain rule as epilogue), the in-layer weight gradient with its bias gradient in the same
+        launch, and the in-layer data gradient accumulated onto d_h in place."""
         plan, dtype, lengths, R = ctx.plan, ctx.dtype, ctx.lengths, ctx.R
         C, WG = K.conv1d_cl_raw, K.conv1d_cl_wgrad_raw
         H, L, k = plan.H, plan.L, plan.k
         saved = list(ctx.saved_tensors)
         grads = [None] * len(R)
-        t = d_out.size(1)
+        b, t = d_out.size(0), d_out.size(1)
         rowmask = (torch.arange(t, device=d_out.device)[None, :, None] < lengths[:, None, None])
-        d_o = (d_out * rowmask).to(dtype).contiguous()          # d(output * x_mask)
+        dcat = torch.empty(b, t, 2 * H, device=d_out.device, dtype=dtype)
+        torch.mul(d_out, rowmask, out=dcat[..., H:]) if d_out.dtype == dtype else dcat[..., H:].copy_(d_out * rowmask)   # d(output * x_mask)
+        d_h, d_o = dcat[..., :H], dcat[..., H:]
         dcond = [] if ctx.has_cond else None
-        d_h = None
         for i in reversed(range(L)):
             acts, pre, h = saved.pop(), saved.pop(), saved.pop()
-            r_in, r_res, r_skip = R[5 * i], R[5 * i + 2], R[5 * i + 3]
+            r_in, r_rs = R[4 * i], R[4 * i + 2]
             d = plan.dils[i]
             pad = (k * d - d) // 2
-            if i == L - 1:
-                db_rs = torch.empty(H, dtype=torch.float32, device=d_o.device)
-                grads[5 * i + 3] = WG(acts, d_o, 1, out=r_skip.dw, dbias=db_rs)
-                grads[5 * i + 4] = db_rs
-                d_pre = C(d_o, WA.bwd_operand(r_skip), None, mg_src=pre, lengths=lengths, flags=K.CONV_GATE_BWD | K.CONV_MASK_OUT, gate_h=H)
-            else:
-                db_rs = torch.empty(2 * H, dtype=torch.float32, device=d_o.device)
-                grads[5 * i + 3] = WG(acts, d_o, 1, out=r_skip.dw, dbias=db_rs[H:])
-                grads[5 * i + 2] = WG(acts, d_h, 1, out=r_res.dw, dbias=db_rs[:H])
-                grads[5 * i + 4] = db_rs
-                # partial d(acts) from the residual branch, held in the left half of a 2H-wide buffer so that
-                # its row pitch equals that of the GATE_BWD output (the kernel shares ldy between y, res, mg_src)
-                tmp = torch.empty_like(pre)[..., :H]
-                C(d_h, WA.bwd_operand(r_res), None, out=tmp)
-                d_pre = C(d_o, WA.bwd_operand(r_skip), None, res=tmp, mg_src=pre, lengths=lengths,
-                          flags=K.CONV_GATE_BWD | K.CONV_MASK_OUT, gate_h=H)
-            grads[5 * i] = WG(h, d_pre, k, dil=d, pad=pad, out=r_in.dw)
-            s_b = d_pre.sum(1, dtype=torch.float32)                       # [b, 2H]: gradient of cond[i]
-            grads[5 * i + 1] = s_b.sum(0)
+            last = i == L - 1
+            dy_rs = d_o if last else dcat
+            db_rs = torch.empty(H if last else 2 * H, dtype=torch.float32, device=d_out.device)
+            grads[4 * i + 2] = WG(acts, dy_rs, 1, out=r_rs.dw, dbias=db_rs)
+            grads[4 * i + 3] = db_rs
+            d_pre = C(dy_rs, WA.bwd_operand(r_rs), None, mg_src=pre, lengths=lengths, flags=K.CONV_GATE_BWD | K.CONV_MASK_OUT, gate_h=H)
+            db_in = torch.empty(2 * H, dtype=torch.float32, device=d_out.device)
+            grads[4 * i] = WG(h, d_pre, k, dil=d, pad=pad, out=r_in.dw, dbias=db_in)
+            grads[4 * i + 1] = db_in
             if dcond is not None:
-                dcond.append(s_b)
-            d_h = C(d_pre, WA.bwd_operand(r_in), None, res=d_h, lengths=lengths, dil=d, pad=pad,
-                    flags=K.CONV_MASK_OUT | (K.CONV_RES_AFTER if d_h is not None else 0))
+                dcond.append(d_pre.sum(1, dtype=torch.float32))           # [b, 2H]: gradient of cond[i]
+            C(d_pre, WA.bwd_operand(r_in), None, res=None if last else d_h, out=d_h, lengths=lengths, dil=d, pad=pad,
+              flags=K.CONV_MASK_OUT | (0 if last else K.CONV_RES_AFTER))
         dc = torch.stack(dcond[::-1], 0) if dcond is not None else None
-        return (None, None, d_h, None, dc, *grads)
+        return (None, None, d_h.contiguous(), None, dc, *grads)
 
 
 def wn_forward_cl(wn, x_cl, lengths, g):
