@@ -133,7 +133,9 @@ class PrepFn(torch.autograd.Function):
         rc = _lib.lib().vits_weight_prep_bwd(arena.table.data_ptr(), arena.n, arena.total_rows, arena.dw.data_ptr(),
                                              arena.dparam.data_ptr(), _lib.stream_ptr())
         _lib.check(rc, "vits_weight_prep_bwd")
-        return (None, *arena.dparam_views)
+        # FRESH views: autograd's AccumulateGrad installs an incoming gradient as param.grad without a copy only when
+        # nobody else references the tensor object; handing out the cached views costs one copy kernel per parameter
+        return (None, *[arena.dparam[o:o + p.numel()].view_as(p) for o, p in zip(arena.p_off, arena.params)])
 
 
 class Resolved:
