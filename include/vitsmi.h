@@ -294,6 +294,18 @@ int vits_absdiff_bwd(int dtype, const void* a, const void* b, size_t n, const fl
                      void* stream);
 int vits_segsum_f32(const float* x, int n_seg, size_t seg_len, float* out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* out[seg][c] = sum_r x[seg][r][c]  (x dense [n_seg][rows][c] of `dtype`, out float32): per-item / whole-batch column sums of a
+ * channels-last tensor — conditioning and bias gradients (torch `dy.sum(1)` / `dy.sum((0,1))`).  Fixed-order, no atomics;
+ * workspace of vits_colsum_workspace(...) bytes (may be 0 when that returns 0... pass the shared scratch). */
+size_t vits_colsum_workspace(int n_seg, int rows, int c);
+int vits_colsum(int dtype, const void* x, int n_seg, int rows, int c, float* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* out = dy * (y > 0 ? 1 : slope), rows t >= lengths[b] zeroed; y and lengths optional; dy, y, out dense [b][t][c] of `dtype`.
+ * The chain rule of vits_conv1d_cl's fused output leaky-relu (VITS_CONV_OUT_LRELU: sign(y) = sign of the pre-activation)
+ * and output mask ahead of the weight / data gradient launches (reference F.leaky_relu, models.py:327,352). */
+int vits_lrelu_mask_bwd(int dtype, const void* dy, const void* y, float slope, const int32_t* lengths, int b, int t, int c,
+                        void* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

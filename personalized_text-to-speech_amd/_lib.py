@@ -10,7 +10,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvitsmi.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_int = ctypes.c_int
 c_void_p = ctypes.c_void_p
@@ -40,6 +40,9 @@ SIGNATURES = {
     "vits_absdiff_sum": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_float, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "vits_absdiff_bwd": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     "vits_segsum_f32": (c_int, [c_void_p, c_int, c_size_t, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "vits_colsum_workspace": (c_size_t, [c_int, c_int, c_int]),
+    "vits_colsum": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "vits_lrelu_mask_bwd": (c_int, [c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vits_conv1d_cl_wgrad_workspace": (c_size_t, [c_int] * 5),
     "vits_conv1d_cl_wgrad": (c_int, [c_void_p, c_void_p]),
     "vits_conv1d_cl": (c_int, [c_void_p, c_void_p]),

@@ -69,6 +69,60 @@ __global__ __launch_bounds__(kThreads) void absdiff_bwd_kernel(const T* __restri
   }
 }
 
+// dy' = dy * (y > 0 ? 1 : slope) (y optional) with rows >= lengths[b] zeroed (lengths optional): the chain rule of a fused output
+// leaky-relu and of an output mask in ONE launch (replaces gt + where + 2 scalar fills + mul + cast, and arange + lt + mul)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void lrelu_mask_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, float slope,
+                                                                 const int* __restrict__ lengths, int t, int c, size_t n,
+                                                                 T* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (size_t)gridDim.x * kThreads) {
+    float v = ld<T>(dy, i);
+    if (y && !(ld<T>(y, i) > 0.f)) v *= slope;
+    if (lengths) {
+      const size_t row = i / c;
+      const int b = (int)(row / t), tt = (int)(row - (size_t)b * t);
+      if (tt >= lengths[b]) v = 0.f;
+    }
+    out[i] = (T)v;
+  }
+}
+
+// column sums of a channels-last tensor: partial[(seg*S + s)*C + c] = sum over the split's rows of x[seg][row][c]
+// block = 64 columns x 4 row lanes; coalesced 128/256-byte row segments
+template <typename T>
+__global__ __launch_bounds__(kThreads) void colsum_kernel(const T* __restrict__ x, int rows, int C, float* __restrict__ dst) {
+  __shared__ float red[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int S = gridDim.y, s = blockIdx.y, seg = blockIdx.z;
+  const int per = (rows + S - 1) / S, r0 = s * per, r1 = (r0 + per < rows) ? r0 + per : rows;
+  const T* base = x + (size_t)seg * rows * C;
+  float acc = 0.f;
+  if (col < C)
+    for (int r = r0 + rl; r < r1; r += 4) acc += ld<T>(base, (size_t)r * C + col);
+  red[rl][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (rl == 0 && col < C) dst[((size_t)seg * S + s) * C + col] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// out[seg][c] = sum_s partial[(seg*S + s)*C + c]
+__global__ __launch_bounds__(kThreads) void colsum_final_kernel(const float* __restrict__ partial, int S, int C, int n_seg, float* __restrict__ out) {
+  const int i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n_seg * C) return;
+  const int seg = i / C, c = i - seg * C;
+  float acc = 0.f;
+  for (int s = 0; s < S; ++s) acc += partial[((size_t)seg * S + s) * C + c];
+  out[i] = acc;
+}
+
+int colsum_splits(int n_seg, int rows, int C) {
+  const int wgs = n_seg * ((C + 63) / 64);
+  int S = (512 + wgs - 1) / wgs;
+  const int max_s = rows / 64 > 0 ? rows / 64 : 1;
+  if (S > max_s) S = max_s;
+  if (S > 64) S = 64;
+  return S < 1 ? 1 : S;
+}
+
 int pick_splits(size_t seg_len, int n_seg) {
   long s = (long)((seg_len + (size_t)kThreads * 8 - 1) / ((size_t)kThreads * 8));     // >= 8 elements per thread
   const long fill = (1024 + n_seg - 1) / n_seg;                                      // ~4 workgroups per CU in total
@@ -128,4 +182,45 @@ extern "C" int vits_segsum_f32(const float* x, int n_seg, size_t seg_len, float*
   hipLaunchKernelGGL((partial_kernel<float, false>), dim3(splits, n_seg), dim3(kThreads), 0, s, x, x, seg_len, part);
   hipLaunchKernelGGL(final_kernel, dim3(n_seg), dim3(64), 0, s, part, splits, 1.0f, out, 0);
   return vits::check_launch("vits_segsum_f32");
+}
+
+extern "C" int vits_lrelu_mask_bwd(int dtype, const void* dy, const void* y, float slope, const int32_t* lengths, int b, int t, int c,
+                                   void* out, void* stream) {
+  if (!dy || !out || b <= 0 || t <= 0 || c <= 0) return VITS_E_BADARG;
+  const size_t n = (size_t)b * t * c;
+  size_t blocks = (n + (size_t)kThreads * 4 - 1) / ((size_t)kThreads * 4);
+  if (blocks > 4096) blocks = 4096;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == VITS_DT_BF16)
+    hipLaunchKernelGGL(lrelu_mask_bwd_kernel<__bf16>, dim3((unsigned)blocks), dim3(kThreads), 0, s, static_cast<const __bf16*>(dy),
+                       static_cast<const __bf16*>(y), slope, lengths, t, c, n, static_cast<__bf16*>(out));
+  else if (dtype == VITS_DT_F32)
+    hipLaunchKernelGGL(lrelu_mask_bwd_kernel<float>, dim3((unsigned)blocks), dim3(kThreads), 0, s, static_cast<const float*>(dy),
+                       static_cast<const float*>(y), slope, lengths, t, c, n, static_cast<float*>(out));
+  else
+    return VITS_E_UNSUPPORTED;
+  return vits::check_launch("vits_lrelu_mask_bwd");
+}
+
+extern "C" size_t vits_colsum_workspace(int n_seg, int rows, int c) {
+  return (size_t)n_seg * colsum_splits(n_seg, rows, c) * c * sizeof(float);
+}
+
+extern "C" int vits_colsum(int dtype, const void* x, int n_seg, int rows, int c, float* out, void* workspace, size_t workspace_bytes,
+                           void* stream) {
+  if (!x || !out || n_seg <= 0 || rows <= 0 || c <= 0) return VITS_E_BADARG;
+  const int S = colsum_splits(n_seg, rows, c);
+  if (S > 1 && (!workspace || workspace_bytes < vits_colsum_workspace(n_seg, rows, c))) return VITS_E_BADARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float* dst = S > 1 ? static_cast<float*>(workspace) : out;
+  dim3 grid((c + 63) / 64, S, n_seg);
+  if (dtype == VITS_DT_BF16)
+    hipLaunchKernelGGL(colsum_kernel<__bf16>, grid, dim3(kThreads), 0, s, static_cast<const __bf16*>(x), rows, c, dst);
+  else if (dtype == VITS_DT_F32)
+    hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(kThreads), 0, s, static_cast<const float*>(x), rows, c, dst);
+  else
+    return VITS_E_UNSUPPORTED;
+  if (S > 1)
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((n_seg * c + kThreads - 1) / kThreads), dim3(kThreads), 0, s, dst, S, c, n_seg, out);
+  return vits::check_launch("vits_colsum");
 }

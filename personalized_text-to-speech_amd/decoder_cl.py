@@ -175,7 +175,7 @@ class DecoderFn(torch.autograd.Function):
             return WG(x, dy, k, out=R[slot].dw, dbias=db, **kw)
 
         def bias_grad(d):
-            return d.sum((0, 1), dtype=torch.float32)
+            return K.colsum(d if d.is_contiguous() else d.contiguous())
 
         y = saved.pop()
         h = saved.pop()
@@ -228,7 +228,7 @@ class DecoderFn(torch.autograd.Function):
         i_pre = idx["pre"]
         grads[i_pre[0]] = WGo(z, dh, 7, i_pre[0], i_pre[1], pad=3)
         dz = C(dh, flip_t(i_pre[0]), None, pad=3)
-        dcond = dh.sum(1, dtype=torch.float32) if ctx.has_cond else None
+        dcond = K.colsum(dh if dh.is_contiguous() else dh.contiguous(), per_item=True) if ctx.has_cond else None
         return (None, None, dz, dcond, *grads)
 
 

@@ -240,6 +240,33 @@ def conv1d_cl_raw(x, w, bias=None, bias_b=None, res=None, mg_src=None, out=None,
     return out
 
 
+def colsum(x, per_item=False):
+    """float32 column sums of a contiguous channels-last [b, t, c] tensor: per item ([b, c]) or over the batch ([c])."""
+    _lib.require_cuda(x)
+    assert x.is_contiguous() and x.dim() == 3
+    b, t, c = x.shape
+    n_seg, rows = (b, t) if per_item else (1, b * t)
+    out = torch.empty((b, c) if per_item else (c,), device=x.device, dtype=torch.float32)
+    L = _lib.lib()
+    nbytes = L.vits_colsum_workspace(n_seg, rows, c)
+    ws = workspace(nbytes, x.device)
+    rc = L.vits_colsum(_DT[x.dtype], x.data_ptr(), n_seg, rows, c, out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+    _lib.check(rc, "vits_colsum")
+    return out
+
+
+def lrelu_mask_bwd(dy, y=None, slope=1.0, lengths=None):
+    """dy * (y > 0 ? 1 : slope) with rows >= lengths zeroed, one launch (vits_lrelu_mask_bwd); dy [b,t,c] contiguous."""
+    _lib.require_cuda(dy)
+    assert dy.is_contiguous() and dy.dim() == 3 and (y is None or (y.is_contiguous() and y.shape == dy.shape and y.dtype == dy.dtype))
+    out = torch.empty_like(dy)
+    b, t, c = dy.shape
+    rc = _lib.lib().vits_lrelu_mask_bwd(_DT[dy.dtype], dy.data_ptr(), None if y is None else y.data_ptr(), float(slope),
+                                        None if lengths is None else lengths.data_ptr(), b, t, c, out.data_ptr(), _lib.stream_ptr())
+    _lib.check(rc, "vits_lrelu_mask_bwd")
+    return out
+
+
 _workspace = {}
 
 

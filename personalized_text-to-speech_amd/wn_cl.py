@@ -66,11 +66,10 @@ class ConvCLFn(torch.autograd.Function):
         dil, pad, in_slope, mask_in, mask_out, stride = ctx.cfg
         k = R.fwd.size(0)
         dy = dy.contiguous()
-        if ctx.out_slope is not None:                   # chain rule of the fused output leaky-relu (sign of y = sign of pre-activation)
-            dy = dy * torch.where(ysave > 0, 1.0, ctx.out_slope).to(dy.dtype)
-        if mask_out:                                    # d(y * mask): zero rows first (one pass, reused)
-            t = dy.size(1)
-            dy = dy * (torch.arange(t, device=dy.device)[None, :, None] < ctx.lengths[:, None, None])
+        if ctx.out_slope is not None or mask_out:
+            # chain rule of the fused output leaky-relu (sign of y = sign of the pre-activation) and of the output mask
+            dy = K.lrelu_mask_bwd(dy, ysave if ctx.out_slope is not None else None, ctx.out_slope if ctx.out_slope is not None else 1.0,
+                                  ctx.lengths if mask_out else None)
         dw = db = None
         want_db = ctx.has_bias and ctx.needs_input_grad[3]
         if ctx.needs_input_grad[2]:
@@ -79,7 +78,7 @@ class ConvCLFn(torch.autograd.Function):
             dw = K.conv1d_cl_wgrad_raw(xd, dy, k, lengths=ctx.lengths, dil=dil, pad=pad, stride=stride, in_slope=in_slope,
                                        flags=K.CONV_MASK_IN if mask_in else 0, out=R.dw, dbias=db, groups=ctx.groups)
         if want_db and db is None:
-            db = dy.sum((0, 1), dtype=torch.float32)
+            db = K.colsum(dy)
         dx = None
         if ctx.needs_input_grad[1]:
             xs = xd if xd.is_contiguous() else xd.contiguous()
@@ -210,7 +209,7 @@ class WNFn(torch.autograd.Function):
             grads[4 * i] = WG(h, d_pre, k, dil=d, pad=pad, out=r_in.dw, dbias=db_in)
             grads[4 * i + 1] = db_in
             if dcond is not None:
-                dcond.append(d_pre.sum(1, dtype=torch.float32))           # [b, 2H]: gradient of cond[i]
+                dcond.append(K.colsum(d_pre, per_item=True))              # [b, 2H]: gradient of cond[i]
             C(d_pre, WA.bwd_operand(r_in), None, res=None if last else d_h, out=d_h, lengths=lengths, dil=d, pad=pad,
               flags=K.CONV_MASK_OUT | (0 if last else K.CONV_RES_AFTER))
         dc = torch.stack(dcond[::-1], 0) if dcond is not None else None

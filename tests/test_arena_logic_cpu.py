@@ -14,6 +14,8 @@ from model_util import build_tiny, inputs, load_tiny, noise_list, oracle_maximum
 def emulated(pkg, monkeypatch):
     dcl = importlib.import_module("personalized_text-to-speech_amd.decoder_cl")
     monkeypatch.setattr(pkg.kernels, "conv1d_cl_raw", cl_emul.conv1d_cl_raw)
+    monkeypatch.setattr(pkg.kernels, "lrelu_mask_bwd", cl_emul.lrelu_mask_bwd)
+    monkeypatch.setattr(pkg.kernels, "colsum", cl_emul.colsum)
     monkeypatch.setattr(pkg.kernels, "conv1d_cl_wgrad_raw", cl_emul.conv1d_cl_wgrad_raw)
     monkeypatch.setattr(pkg.kernels, "maximum_path", oracle_maximum_path)
     monkeypatch.setattr(dcl, "convt_fold", cl_emul.convt_fold)

@@ -11,6 +11,8 @@ from oracle import vits_torch as O
 @pytest.fixture()
 def emulated(pkg, monkeypatch):
     monkeypatch.setattr(pkg.kernels, "conv1d_cl_raw", cl_emul.conv1d_cl_raw)
+    monkeypatch.setattr(pkg.kernels, "lrelu_mask_bwd", cl_emul.lrelu_mask_bwd)
+    monkeypatch.setattr(pkg.kernels, "colsum", cl_emul.colsum)
     monkeypatch.setattr(pkg.kernels, "conv1d_cl_wgrad_raw", cl_emul.conv1d_cl_wgrad_raw)
     cl_emul.install_rowops(monkeypatch)
     cl_emul.install_attention(monkeypatch)

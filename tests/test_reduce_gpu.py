@@ -66,3 +66,27 @@ def test_mpd_feature_loss_uses_fused_path_and_matches(pkg):
     (ga,) = torch.autograd.grad(fused, y_hat, retain_graph=True)
     (gb,) = torch.autograd.grad(plain, y_hat)
     assert float((ga - gb).norm() / gb.norm()) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_lrelu_mask_bwd(pkg, dtype):
+    import cl_emul
+    torch.manual_seed(4)
+    dy = torch.randn(5, 37, 24, device=DEV).to(dtype)
+    y = torch.randn(5, 37, 24, device=DEV).to(dtype)
+    lens = torch.tensor([37, 1, 20, 36, 5], device=DEV, dtype=torch.int32)
+    for yy, sl, ll in [(y, 0.1, None), (None, 1.0, lens), (y, 0.2, lens)]:
+        a, b = pkg.kernels.lrelu_mask_bwd(dy, yy, sl, ll), cl_emul.lrelu_mask_bwd(dy, yy, sl, ll)
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_colsum(pkg, dtype):
+    torch.manual_seed(6)
+    for shape in [(16, 500, 384), (16, 8192, 32), (3, 7, 5), (16, 256, 256), (1, 1, 8)]:
+        x = torch.randn(*shape, device=DEV).to(dtype)
+        a, b = pkg.kernels.colsum(x), x.double().sum((0, 1))
+        assert a.dtype == torch.float32 and torch.allclose(a.double(), b, rtol=1e-4, atol=1e-2)
+        a, b = pkg.kernels.colsum(x, per_item=True), x.double().sum(1)
+        assert a.shape == b.shape and torch.allclose(a.double(), b, rtol=1e-4, atol=1e-2)
+        assert torch.equal(pkg.kernels.colsum(x), pkg.kernels.colsum(x))
