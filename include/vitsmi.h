@@ -154,6 +154,10 @@ typedef struct vits_wgrad_desc {
   const void* x;  const void* dy;  float* dw;  void* workspace;  size_t workspace_bytes;
   const int32_t* lengths;
   float* dbias;             /* optional float32[c_out]: (+)= sum_{b,t} dy[b][t][co] (rows masked like dy), same launch */
+  int32_t* counters;        /* optional: >= (c_out/64)*(c_in/64)*taps ints, ZERO before the first use and owned by one stream: the last
+                               split to finish a tile then sums the slabs itself (same fixed order, same bits) and re-arms its
+                               counter, so the call is ONE launch; without it a second launch sums the slabs              */
+  size_t counters_len;
 } vits_wgrad_desc;
 
 size_t vits_conv1d_cl_wgrad_workspace(int b, int t_out, int c_in, int c_out, int k);

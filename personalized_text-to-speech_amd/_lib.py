@@ -10,7 +10,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvitsmi.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 c_int = ctypes.c_int
 c_void_p = ctypes.c_void_p
@@ -69,7 +69,7 @@ class WgradDesc(ctypes.Structure):
                                               "ldx", "lddy")] + \
                [("in_slope", c_float), ("groups", ctypes.c_int32)] + \
                [("x", c_void_p), ("dy", c_void_p), ("dw", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_size_t),
-                ("lengths", c_void_p), ("dbias", c_void_p)]
+                ("lengths", c_void_p), ("dbias", c_void_p), ("counters", c_void_p), ("counters_len", c_size_t)]
 
 
 _lib = None

@@ -36,6 +36,8 @@ struct WgradArgs {
   int flags;
   int ldx, lddy, stride;
   int groups;             // > 1: block-diagonal only, compact dw [k][c_out][c_in/groups]
+  int* counters;          // non-null: the last split to finish a tile sums the slabs itself (fixed order), see below
+  float* dw_final; float* db_final; int accumulate;
   float* partial_db;      // per-split bias-gradient sums (slab pitch `slab`), or null
   size_t slab;            // floats per split in `partial` (dw slab, optionally followed by the db slab)
 };
@@ -288,23 +290,64 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
   // slab of this split: partial[split][tap][co][ci]
   float* P = a.partial + (size_t)blockIdx.x * a.slab;
   const int ci = ci0 + wj * 32 + r;
-  if (ci < a.Cin && (!SMALL || wave == 0)) {
+  const bool writer = ci < a.Cin && (!SMALL || wave == 0);
+  // element index of accumulator (k, i) in dw's layout (dense, or compact for grouped layers); -1 = not an element of dw
+  auto index_of = [&](int k, int i) -> long {
+    const int co = co0 + wi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+    if (co >= a.Cout) return -1;
+    if (a.groups > 1) {
+      const int ci_lo = (co / og) * ig;
+      if (ci < ci_lo || ci >= ci_lo + ig) return -1;
+      return ((long)(tap0 + k) * a.Cout + co) * ig + (ci - ci_lo);
+    }
+    return ((long)(tap0 + k) * a.Cout + co) * a.Cin + ci;
+  };
+  if (writer) {
 #pragma unroll
     for (int k = 0; k < KT; ++k)
       if (k < ntap) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const int co = co0 + wi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-          if (co >= a.Cout) continue;
-          if (a.groups > 1) {
-            const int ci_lo = (co / og) * ig;
-            if (ci >= ci_lo && ci < ci_lo + ig) P[((size_t)(tap0 + k) * a.Cout + co) * ig + (ci - ci_lo)] = acc[k][i];
-          } else {
-            P[((size_t)(tap0 + k) * a.Cout + co) * a.Cin + ci] = acc[k][i];
-          }
+          const long idx = index_of(k, i);
+          if (idx >= 0) P[idx] = acc[k][i];
         }
       }
   }
+  if (a.counters == nullptr) return;
+
+  // Fused second stage: every split publishes its slab (release), the LAST split to arrive at this tile sums the S slabs
+  // in split order — the same fixed order as reduce_slabs, so the result is bitwise independent of which split is last —
+  // and re-arms the counter for the next launch (no zero-fill between launches, nothing for a graph replay to forget).
+  __shared__ int is_last;
+  __threadfence();
+  __syncthreads();
+  const int tile = blockIdx.y * gridDim.z + blockIdx.z;
+  if (tid == 0) is_last = (atomicAdd(&a.counters[tile], 1) == a.S - 1);
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();
+  const float* base = a.partial;
+  if (writer) {
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+      if (k < ntap) {
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+          const long idx = index_of(k, i);
+          if (idx < 0) continue;
+          float sum = a.accumulate ? a.dw_final[idx] : 0.f;
+          for (int sp = 0; sp < a.S; ++sp) sum += __builtin_nontemporal_load(base + (size_t)sp * a.slab + idx);
+          a.dw_final[idx] = sum;
+        }
+      }
+  }
+  if (do_db && tid < 64 && co0 + tid < a.Cout) {
+    float sum = a.accumulate ? a.db_final[co0 + tid] : 0.f;
+    const float* pb = a.partial_db + co0 + tid;
+    for (int sp = 0; sp < a.S; ++sp) sum += __builtin_nontemporal_load(pb + (size_t)sp * a.slab);
+    a.db_final[co0 + tid] = sum;
+  }
+  if (tid == 0) a.counters[tile] = 0;
 }
 
 // out[i] (+)= sum_s partial[s * slab + i] in a fixed order; elements i < n go to dw, the following nb to db.
@@ -347,13 +390,13 @@ int launch(const WgradArgs& a, hipStream_t s) {
   constexpr int PITCH = Pitch<T>::value;
   size_t lds = FLAT ? (size_t)(1 + KT) * TK * PITCH : (size_t)(TK + (TK - 1) * a.stride + (KT - 1) * a.dil + 1) * PITCH;
   if (SMALL && lds < (size_t)3 * KT * 16 * 64 * 4) lds = (size_t)3 * KT * 16 * 64 * 4;
-  if (lds > (size_t)vits::kLdsBytesMax) return VITS_E_UNSUPPORTED;
+  if (lds > (size_t)vits::kLdsBytesMax - 256) return VITS_E_UNSUPPORTED;      // minus the kernel's static LDS
   auto kern = wgrad_kernel<T, KT, SMALL, FLAT>;
   // once per kernel instance, to the hardware maximum: a per-launch value would be whatever the LAST call set by
   // the time a captured graph replays its nodes
   static bool lds_attr_set = false;
   if (!lds_attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, vits::kLdsBytesMax);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, vits::kLdsBytesMax - 256);
     if (e != hipSuccess) return vits::note_hip_error(e, "vits_conv1d_cl_wgrad/attr");
     lds_attr_set = true;
   }
@@ -417,8 +460,14 @@ extern "C" int vits_conv1d_cl_wgrad(const vits_wgrad_desc* desc, void* stream) {
   const bool accumulate = (d.flags & VITS_CONV_ACCUM) != 0;
   const bool direct = (S == 1) && !accumulate;           // a single split writes dw / db itself: no second launch
   float* ws = static_cast<float*>(d.workspace);
+  // fused second stage (the last split of a tile sums the slabs): needs one zero-initialised, self-re-arming counter per tile
+  const bool flat_k = flat;
+  const int kt = flat_k ? (d.k < KT_FLAT ? d.k : KT_FLAT) : taps_per_group(d.k);
+  const size_t tiles = (size_t)vits::ceil_div(d.c_out, CT) * (d.groups > 1 ? 1 : vits::ceil_div(d.c_in, CT)) * vits::ceil_div(d.k, kt);
+  const bool fused = !direct && d.counters != nullptr && d.counters_len >= tiles;
   WgradArgs a{d.x, d.dy, direct ? d.dw : ws, d.lengths, d.b, d.t, t_out, d.c_in, d.c_out, d.k, d.dil, d.pad,
               S, vits::ceil_div(t_out, TK), d.in_slope, d.flags, d.ldx, d.lddy, d.stride, d.groups,
+              fused ? d.counters : nullptr, d.dw, d.dbias, accumulate ? 1 : 0,
               d.dbias ? (direct ? d.dbias : ws + n) : nullptr, direct ? 0 : n + nb};
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc;
@@ -432,7 +481,7 @@ extern "C" int vits_conv1d_cl_wgrad(const vits_wgrad_desc* desc, void* stream) {
     return VITS_E_UNSUPPORTED;
   }
   if (rc != VITS_OK) return rc;
-  if (direct) return VITS_OK;
+  if (direct || fused) return VITS_OK;
   hipLaunchKernelGGL(reduce_slabs, dim3((unsigned)(((n + nb) / 4 + 255) / 256)), dim3(256), 0, s, a.partial, d.dw, d.dbias, n, nb,
                      a.slab, a.S, accumulate ? 1 : 0);
   return vits::check_launch("vits_conv1d_cl_wgrad/reduce");

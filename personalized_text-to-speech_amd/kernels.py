@@ -271,11 +271,30 @@ _workspace = {}
 
 
 def workspace(nbytes, device):
-    """Grow-only device scratch shared by the kernels that need one (stream-ordered reuse)."""
-    buf = _workspace.get(device)
+    """Grow-only device scratch for the kernels that need one: one buffer per (device, stream), reused in stream order
+    (independent branches of the step run on their own streams and must not share slabs)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream) if torch.device(device).type == "cuda" else (device, 0)
+    buf = _workspace.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
-        _workspace[device] = buf
+        _workspace[key] = buf
+    return buf
+
+
+_counters = {}
+# Measured: correct (bitwise equal to the two-launch result, tests/test_conv_gpu.py) but 3x SLOWER for the whole step: the
+# agent-scope release/acquire fences the hand-off needs write back / invalidate a whole XCD's L2 on gfx950, once per
+# workgroup.  Left as an opt-in experiment; the default sums the slabs in a second launch.
+FUSED_WGRAD_REDUCE = False
+
+
+def tile_counters(device):
+    """Zero-initialised, self-re-arming per-tile counters of vits_conv1d_cl_wgrad's fused slab reduction: one buffer per
+    (device, stream), like the scratch."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _counters.get(key)
+    if buf is None:
+        buf = _counters[key] = torch.zeros(1 << 16, dtype=torch.int32, device=device)
     return buf
 
 
@@ -301,6 +320,9 @@ def conv1d_cl_wgrad_raw(x, dy, k, lengths=None, dil=1, pad=0, stride=1, in_slope
                        x=x.data_ptr(), dy=dy.data_ptr(), dw=out.data_ptr(), workspace=ws.data_ptr(), workspace_bytes=ws.numel(),
                        lengths=None if lengths is None else lengths.data_ptr(),
                        dbias=None if dbias is None else dbias.data_ptr())
+    if FUSED_WGRAD_REDUCE:
+        cnt = tile_counters(x.device)
+        d.counters, d.counters_len = cnt.data_ptr(), cnt.numel()
     assert dbias is None or (dbias.dtype == torch.float32 and dbias.is_contiguous() and dbias.numel() == c_out)
     import ctypes
     e0 = _lib.timer.start("vits_conv1d_cl_wgrad")

@@ -262,3 +262,29 @@ def test_grouped_convolution_on_dense_operands(pkg, dtype, tol):
         assert rel(db, dy.float().sum((0, 1))) < tol
         ge = cl_emul.conv1d_cl_wgrad_raw(x, dy, kk, pad=pd, stride=st, groups=groups)
         assert rel(ge, dw_ref.permute(2, 0, 1)) < tol
+
+
+def test_wgrad_fused_reduction_is_bitwise_the_two_launch_result(pkg):
+    """The last-split-sums-the-slabs path must give exactly the bits of the separate reduce_slabs launch (same fixed order),
+    repeatedly (the per-tile counters re-arm themselves), with and without accumulation and bias gradient."""
+    K = pkg.kernels
+    torch.manual_seed(12)
+    for (b, t, ci, co, kk, st, pd, dt) in [(16, 500, 192, 384, 5, 1, 2, torch.bfloat16), (16, 500, 192, 192, 1, 1, 0, torch.bfloat16),
+                                           (64, 51, 1024, 1024, 5, 1, 2, torch.bfloat16), (4, 300, 64, 96, 3, 1, 1, torch.float32),
+                                           (16, 2048, 32, 32, 7, 1, 3, torch.bfloat16)]:
+        x = torch.randn(b, t, ci, device=DEV).to(dt)
+        dy = torch.randn(b, (t + 2 * pd - kk) // st + 1, co, device=DEV).to(dt)
+        res = {}
+        for fused in (False, True, True):
+            K.FUSED_WGRAD_REDUCE = fused
+            try:
+                db = torch.empty(co, device=DEV)
+                dw = K.conv1d_cl_wgrad_raw(x, dy, kk, pad=pd, stride=st, dbias=db)
+                acc = dw.clone(); dba = db.clone()
+                K.conv1d_cl_wgrad_raw(x, dy, kk, pad=pd, stride=st, dbias=dba, out=acc, flags=K.CONV_ACCUM)
+            finally:
+                K.FUSED_WGRAD_REDUCE = False
+            if fused in res:
+                assert all(torch.equal(u, v) for u, v in zip(res[fused], (dw, db, acc, dba)))
+            res[fused] = (dw, db, acc, dba)
+        assert all(torch.equal(u, v) for u, v in zip(res[False], res[True])), (b, t, ci, co, kk)
