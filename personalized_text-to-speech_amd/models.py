@@ -76,7 +76,7 @@ class StochasticDurationPredictor(nn.Module):
         if not reverse:
             assert w is not None
             w_cl = w.transpose(1, 2).float()                           # [b, t, 1]
-            h_w = (w_cl * self.post_pre.weight.view(1, 1, -1) + self.post_pre.bias).to(dtype)
+            h_w = wn_cl.conv_cl(F.pad(w_cl, (0, 7)).to(dtype), wn_cl.weight_of(self.post_pre, pad_in=7), self.post_pre.bias, dtype=dtype)
             h_w = self.post_convs.forward_cl(h_w, lengths, m)
             h_w = wn_cl.conv_cl(h_w, wn_cl.weight_of(self.post_proj), self.post_proj.bias, lengths, mask_out=True, dtype=dtype)
             e_q = noise.randn(w.size(0), 2, w.size(2), device=x.device, dtype=torch.float32).transpose(1, 2) * m
@@ -133,6 +133,35 @@ class DurationPredictor(nn.Module):
         return self.proj(x * x_mask) * x_mask
 
 
+class _EmbeddingScaledFn(torch.autograd.Function):
+    """emb(idx) * scale with the weight gradient as a one-hot product on this library's fp32 weight-gradient kernel:
+    torch's embedding backward sorts the 3 216 token ids of a batch (rocprim scan + device memsets — what a replayed graph
+    cannot rely on) and is not the bottleneck either way."""
+
+    @staticmethod
+    def forward(ctx, idx, weight, scale):
+        ctx.save_for_backward(idx)
+        ctx.scale, ctx.shape = scale, weight.shape
+        return F.embedding(idx, weight.detach()) * scale
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        v, h = ctx.shape
+        vp = (v + 7) // 8 * 8
+        n = idx.numel()
+        onehot = (idx.reshape(n, 1) == torch.arange(vp, device=idx.device)[None, :]).to(torch.float32).view(1, n, vp)
+        dyf = (dy.float() * ctx.scale).reshape(1, n, h).contiguous()
+        dw = K.conv1d_cl_wgrad_raw(onehot, dyf, 1)                         # [1][h][vp] = sum_n dy[n][:] (x) onehot[n][:]
+        return None, dw[0].t()[:v].contiguous(), None
+
+
+def _embedding_scaled(idx, weight, scale):
+    if idx.is_cuda:
+        return _EmbeddingScaledFn.apply(idx, weight, scale)
+    return F.embedding(idx, weight) * scale
+
+
 class TextEncoder(nn.Module):
     # models.py:135-176
     def __init__(self, n_vocab, out_channels, hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout):
@@ -145,7 +174,7 @@ class TextEncoder(nn.Module):
         self.proj = Conv1d(hidden_channels, out_channels * 2, 1)
 
     def forward(self, x, x_lengths):
-        x = self.emb(x) * math.sqrt(self.hidden_channels)         # [b, t, h]
+        x = _embedding_scaled(x, self.emb.weight, math.sqrt(self.hidden_channels))         # [b, t, h]
         x = torch.transpose(x, 1, -1)                             # [b, h, t]
         x_mask = torch.unsqueeze(commons.sequence_mask(x_lengths, x.size(2)), 1).to(x.dtype)
         x = self.encoder(x * x_mask, x_mask)
@@ -564,10 +593,10 @@ class SynthesizerTrn(nn.Module):
         # stochastic duration predictor: every 192-channel 1x1 convolution; the 29-column spline projections padded to 32
         if isinstance(net.dp, StochasticDurationPredictor):
             dp = net.dp
-            specs += [Spec(dp.pre), Spec(dp.proj), Spec(dp.post_proj)] + dds_specs(dp.convs) + dds_specs(dp.post_convs)
+            specs += [Spec(dp.pre), Spec(dp.proj), Spec(dp.post_proj), Spec(dp.post_pre, c_in_p=8)] + dds_specs(dp.convs) + dds_specs(dp.post_convs)
             for fl in list(dp.flows) + list(dp.post_flows):
                 if isinstance(fl, modules.ConvFlow):
-                    specs += dds_specs(fl.convs) + [Spec(fl.proj, c_out_p=(fl.proj.out_channels + 7) // 8 * 8)]
+                    specs += dds_specs(fl.convs) + [Spec(fl.pre, c_in_p=8), Spec(fl.proj, c_out_p=(fl.proj.out_channels + 7) // 8 * 8)]
         for fl in net.flow.flows:
             if isinstance(fl, modules.ResidualCouplingLayer):
                 specs += [Spec(fl.pre)] + wn_specs(fl.enc) + [Spec(fl.post)]

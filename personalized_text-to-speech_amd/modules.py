@@ -334,7 +334,9 @@ class ConvFlow(nn.Module):
         dtype = wn_cl.compute_dtype()
         b, t, _ = x.shape
         x0, x1 = x[..., :1], x[..., 1:]
-        h = (x0 * self.pre.weight.view(1, 1, -1) + self.pre.bias).to(dtype)               # Conv1d(1, C, 1): outer product
+        # Conv1d(1, C, 1): the single input channel is padded to the 8-wide vector (zero weights there) so that the layer and
+        # both of its gradients run on the matrix-core kernels (the broadcast form costs two full-tensor torch reductions)
+        h = wn_cl.conv_cl(F.pad(x0, (0, 7)).to(dtype), wn_cl.weight_of(self.pre, pad_in=7), self.pre.bias, dtype=dtype)
         h = self.convs.forward_cl(h, lengths, mask_cl, g)
         n_par = self.num_bins * 3 - 1
         pad = (-n_par) % 8                                                                   # 29 -> 32 output columns

@@ -152,3 +152,16 @@ def test_captured_step_replays_reproducibly(pkg):
     for _ in range(3):
         out = ft.replay()
     assert all(np.isfinite([float(v) for v in out.values()]))
+
+
+def test_text_embedding_gradient_matches_torch(pkg):
+    torch.manual_seed(8)
+    w = torch.randn(111, 192, device="cuda", requires_grad=True)
+    idx = torch.randint(0, 111, (16, 201), device="cuda")
+    g = torch.randn(16, 201, 192, device="cuda")
+    a = pkg.models._embedding_scaled(idx, w, 13.856)
+    b = torch.nn.functional.embedding(idx, w) * 13.856
+    assert torch.equal(a, b)
+    (ga,) = torch.autograd.grad(a, w, g)
+    (gb,) = torch.autograd.grad(b, w, g)
+    assert float((ga - gb).abs().max() / gb.abs().max()) < 1e-5
