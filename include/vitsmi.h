@@ -163,6 +163,18 @@ typedef struct vits_wgrad_desc {
 size_t vits_conv1d_cl_wgrad_workspace(int b, int t_out, int c_in, int c_out, int k);
 int vits_conv1d_cl_wgrad(const vits_wgrad_desc* desc, void* stream);
 
+/* The same call with its second stage (the fixed-order sum of the per-split slabs) DEFERRED: `pending` (host memory) receives
+ * what vits_wgrad_reduce_pending needs; the workspace of a deferred call must stay untouched until that runs.  A fused layer
+ * node issues all its weight gradients deferred and sums them in one launch at the end of its backward (bitwise the same
+ * result as the immediate form).  pending->splits == 0: the call wrote dw itself, nothing is pending. */
+typedef struct vits_wgrad_pending {
+  const float* partial;  float* dw;  float* dbias;
+  size_t n, nb, slab;       /* elements of dw, of dbias (0 if none), floats per split slab                                  */
+  int32_t splits, accumulate;
+} vits_wgrad_pending;
+int vits_conv1d_cl_wgrad_deferred(const vits_wgrad_desc* desc, void* stream, vits_wgrad_pending* pending);
+int vits_wgrad_reduce_pending(const vits_wgrad_pending* list, int count, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Channels-last ConvTranspose1d = 1x1 matrix-core product + overlap-add.
  *

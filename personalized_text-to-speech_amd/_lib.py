@@ -10,7 +10,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvitsmi.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 c_int = ctypes.c_int
 c_void_p = ctypes.c_void_p
@@ -45,6 +45,8 @@ SIGNATURES = {
     "vits_lrelu_mask_bwd": (c_int, [c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vits_conv1d_cl_wgrad_workspace": (c_size_t, [c_int] * 5),
     "vits_conv1d_cl_wgrad": (c_int, [c_void_p, c_void_p]),
+    "vits_conv1d_cl_wgrad_deferred": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "vits_wgrad_reduce_pending": (c_int, [c_void_p, c_int, c_void_p]),
     "vits_conv1d_cl": (c_int, [c_void_p, c_void_p]),
 }
 
@@ -61,6 +63,12 @@ class PrepEntry(ctypes.Structure):
     """vits_prep_entry of include/vitsmi.h"""
     _fields_ = [("v", c_void_p), ("g", c_void_p), ("off", ctypes.c_int64), ("off_dv", ctypes.c_int64), ("off_dg", ctypes.c_int64)] + \
                [(n, ctypes.c_int32) for n in ("layout", "c_out", "c_in", "k", "c_out_p", "c_in_p", "row_lo", "n_rows", "row0", "groups")]
+
+
+class WgradPending(ctypes.Structure):
+    """vits_wgrad_pending of include/vitsmi.h"""
+    _fields_ = [("partial", c_void_p), ("dw", c_void_p), ("dbias", c_void_p), ("n", c_size_t), ("nb", c_size_t), ("slab", c_size_t),
+                ("splits", ctypes.c_int32), ("accumulate", ctypes.c_int32)]
 
 
 class WgradDesc(ctypes.Structure):

@@ -365,6 +365,25 @@ __global__ void reduce_slabs(const float* __restrict__ partial, float* __restric
   *reinterpret_cast<float4*>(dst) = acc;
 }
 
+// All second stages of a group of weight-gradient calls in ONE launch (vits_wgrad_reduce_pending): the table travels by value
+// in the kernel arguments (no device table to upload, nothing for a captured graph to keep alive).
+constexpr int kMaxPending = 48;
+struct PendingTable { vits_wgrad_pending e[kMaxPending]; };
+
+__global__ void reduce_pending_kernel(PendingTable tab) {
+  const vits_wgrad_pending& p = tab.e[blockIdx.y];
+  const size_t total = p.n + p.nb;
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < total; i += (size_t)gridDim.x * blockDim.x * 4) {
+    float* dst = (i < p.n) ? p.dw + i : p.dbias + (i - p.n);
+    float4 acc = p.accumulate ? *reinterpret_cast<const float4*>(dst) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < p.splits; ++k) {
+      const float4 v = *reinterpret_cast<const float4*>(p.partial + (size_t)k * p.slab + i);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4*>(dst) = acc;
+  }
+}
+
 int taps_per_group(int k) { return k <= 4 ? k : (k <= 8 ? (k + 1) / 2 : 4); }
 
 // Number of (b,t)-reduction splits: enough workgroups to fill the chip (together with the tile and tap-group
@@ -429,7 +448,37 @@ extern "C" size_t vits_conv1d_cl_wgrad_workspace(int b, int t_out, int c_in, int
   return (size_t)pick_splits(b, t_out, c_in, c_out, k) * ((size_t)k * c_out * c_in + c_out) * sizeof(float);
 }
 
-extern "C" int vits_conv1d_cl_wgrad(const vits_wgrad_desc* desc, void* stream) {
+static int wgrad_impl(const vits_wgrad_desc* desc, void* stream, vits_wgrad_pending* pending);
+
+extern "C" int vits_conv1d_cl_wgrad(const vits_wgrad_desc* desc, void* stream) { return wgrad_impl(desc, stream, nullptr); }
+
+extern "C" int vits_conv1d_cl_wgrad_deferred(const vits_wgrad_desc* desc, void* stream, vits_wgrad_pending* pending) {
+  if (!pending) return VITS_E_BADARG;
+  pending->splits = 0;
+  return wgrad_impl(desc, stream, pending);
+}
+
+extern "C" int vits_wgrad_reduce_pending(const vits_wgrad_pending* list, int count, void* stream) {
+  if (!list || count < 0) return VITS_E_BADARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  for (int i0 = 0; i0 < count; i0 += kMaxPending) {
+    PendingTable tab;
+    int m = 0;
+    size_t longest = 0;
+    for (int i = i0; i < count && m < kMaxPending; ++i) {
+      if (list[i].splits <= 0) continue;               // that call wrote dw itself
+      tab.e[m++] = list[i];
+      if (list[i].n + list[i].nb > longest) longest = list[i].n + list[i].nb;
+    }
+    if (m == 0) continue;
+    unsigned bx = (unsigned)((longest / 4 + 255) / 256);
+    if (bx > 256) bx = 256;
+    hipLaunchKernelGGL(reduce_pending_kernel, dim3(bx, m), dim3(256), 0, s, tab);
+  }
+  return vits::check_launch("vits_wgrad_reduce_pending");
+}
+
+static int wgrad_impl(const vits_wgrad_desc* desc, void* stream, vits_wgrad_pending* pending) {
   if (!desc) return VITS_E_BADARG;
   vits_wgrad_desc d = *desc;
   if (!d.x || !d.dy || !d.dw || !d.workspace || d.b <= 0 || d.t <= 0 || d.c_in <= 0 || d.c_out <= 0 || d.k <= 0 ||
@@ -482,6 +531,10 @@ extern "C" int vits_conv1d_cl_wgrad(const vits_wgrad_desc* desc, void* stream) {
   }
   if (rc != VITS_OK) return rc;
   if (direct || fused) return VITS_OK;
+  if (pending) {                                         // second stage deferred to vits_wgrad_reduce_pending
+    *pending = vits_wgrad_pending{a.partial, d.dw, d.dbias, n, nb, a.slab, a.S, accumulate ? 1 : 0};
+    return VITS_OK;
+  }
   hipLaunchKernelGGL(reduce_slabs, dim3((unsigned)(((n + nb) / 4 + 255) / 256)), dim3(256), 0, s, a.partial, d.dw, d.dbias, n, nb,
                      a.slab, a.S, accumulate ? 1 : 0);
   return vits::check_launch("vits_conv1d_cl_wgrad/reduce");

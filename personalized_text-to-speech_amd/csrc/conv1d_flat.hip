@@ -10,6 +10,7 @@
 //     rows are enumerated phase-major (t mod s), so inside a tile only the taps with
 //     (phase + tap*dil - pad') % s == 0 are non-zero and the others are skipped entirely (no zero-insertion,
 //     no wasted MFMAs).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -53,7 +54,10 @@ __device__ __forceinline__ u32x4 lrelu_vec(u32x4 raw, float slope) {
   return out.u;
 }
 
-template <typename T, int NT, int WM>
+// WR = 32-row blocks per wave: WR = 2 gives every wave a 64 x (32*NT) tile, so one A and one B fragment read from LDS feed
+// two MFMAs each (LDS reads per MFMA: (WR + NT) / (WR * NT) — 1.5 for 1x2, 1.0 for 2x2): the large discriminator layers are
+// LDS-read-bound, not MFMA-bound.
+template <typename T, int NT, int WM, int WR>
 __global__ __launch_bounds__(kThreads) void conv1d_flat_kernel(FlatArgs args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int taplist[KMAX];
@@ -61,7 +65,7 @@ __global__ __launch_bounds__(kThreads) void conv1d_flat_kernel(FlatArgs args) {
   const vits_conv_desc& a = args.d;
   constexpr int V = Elem<T>::VEC;
   constexpr int KC = Elem<T>::KC;
-  constexpr int WN = 4 / WM, TMW = 32 * WM, TNW = 32 * NT, TN = TNW * WN;
+  constexpr int WN = 4 / WM, TMW = 32 * WM * WR, TNW = 32 * NT, TN = TNW * WN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave % WM, wn = wave / WM;
   const int r = lane & 31, h = lane >> 5;
@@ -111,11 +115,13 @@ __global__ __launch_bounds__(kThreads) void conv1d_flat_kernel(FlatArgs args) {
     decode(row, xs_b[i], xs_t[i]);
   }
 
-  f32x16 acc[NT];
+  f32x16 acc[WR][NT];
 #pragma unroll
-  for (int n = 0; n < NT; ++n)
+  for (int q = 0; q < WR; ++q)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[q][n][i] = 0.f;
 
   const int n_groups = (n_taps + args.G - 1) / args.G;
   // grouped convolution on dense block-diagonal operands: this tile of output channels only sees the input
@@ -191,24 +197,29 @@ __global__ __launch_bounds__(kThreads) void conv1d_flat_kernel(FlatArgs args) {
     if (has_next) load_stage(nci0, ng0);
     const int ntap = (n_taps - g0 < args.G) ? (n_taps - g0) : args.G;
     for (int tl = 0; tl < ntap; ++tl) {
-      const unsigned char* xa = ldsX + (tl * TMW + wm * 32 + r) * PITCH + 16 * h;
+      const unsigned char* xa = ldsX + (tl * TMW + wm * 32 * WR + r) * PITCH + 16 * h;
       const unsigned char* wb = ldsW + (tl * TN + wn * TNW + r) * PITCH + 16 * h;
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
-        const u32x4 av = *reinterpret_cast<const u32x4*>(xa + 32 * m);
+        u32x4 av[WR];
+#pragma unroll
+        for (int q = 0; q < WR; ++q) av[q] = *reinterpret_cast<const u32x4*>(xa + q * 32 * PITCH + 32 * m);
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
           const u32x4 bv = *reinterpret_cast<const u32x4*>(wb + n * 32 * PITCH + 32 * m);
-          if constexpr (sizeof(T) == 2) {
-            union { u32x4 u; bf16x8 v; } ua, ub;
-            ua.u = av; ub.u = bv;
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.v, ub.v, acc[n], 0, 0, 0);
-          } else {
-            union { u32x4 u; float f[4]; } ua, ub;
-            ua.u = av; ub.u = bv;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-              acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua.f[j], ub.f[j], acc[n], 0, 0, 0);
+          for (int q = 0; q < WR; ++q) {
+            if constexpr (sizeof(T) == 2) {
+              union { u32x4 u; bf16x8 v; } ua, ub;
+              ua.u = av[q]; ub.u = bv;
+              acc[q][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.v, ub.v, acc[q][n], 0, 0, 0);
+            } else {
+              union { u32x4 u; float f[4]; } ua, ub;
+              ua.u = av[q]; ub.u = bv;
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                acc[q][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua.f[j], ub.f[j], acc[q][n], 0, 0, 0);
+            }
           }
         }
       }
@@ -225,9 +236,11 @@ __global__ __launch_bounds__(kThreads) void conv1d_flat_kernel(FlatArgs args) {
   const T* R = static_cast<const T*>(a.res);
   const T* MG = static_cast<const T*>(a.mg_src);
 #pragma unroll
+  for (int q = 0; q < WR; ++q)
+#pragma unroll
   for (int i = 0; i < 16; ++i) {
     int b, t;
-    decode(wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h, b, t);
+    decode((wm * WR + q) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h, b, t);
     if (t < 0) continue;
     const int len = a.lengths ? a.lengths[b] : Tout;
 #pragma unroll
@@ -235,7 +248,7 @@ __global__ __launch_bounds__(kThreads) void conv1d_flat_kernel(FlatArgs args) {
       const int co = co0 + (wn * NT + n) * 32 + r;
       if (co >= a.c_out) continue;
       const size_t o = ((size_t)b * Tout + t) * a.ldy + co;
-      float v = acc[n][i];
+      float v = acc[q][n][i];
       if (a.bias) v += a.bias[co];
       if (a.bias_b) v += a.bias_b[(size_t)b * a.c_out + co];
       const bool res_after = (a.flags & VITS_CONV_RES_AFTER) != 0;
@@ -252,9 +265,9 @@ __global__ __launch_bounds__(kThreads) void conv1d_flat_kernel(FlatArgs args) {
   }
 }
 
-template <typename T, int NT, int WM>
+template <typename T, int NT, int WM, int WR = 1>
 int launch_flat(const vits_conv_desc& d, int t_out, hipStream_t s) {
-  constexpr int WN = 4 / WM, TMW = 32 * WM, TN = 32 * NT * WN;
+  constexpr int WN = 4 / WM, TMW = 32 * WM * WR, TN = 32 * NT * WN;
   FlatArgs args{d, t_out, 1, 1, 1, 1};
   const int in_div = d.in_div > 1 ? d.in_div : 1;
   args.phases = (in_div > 1 && d.stride == 1) ? in_div : 1;
@@ -268,7 +281,7 @@ int launch_flat(const vits_conv_desc& d, int t_out, hipStream_t s) {
   args.G = G;
   const size_t lds = (size_t)G * (TMW + TN) * PITCH;
   if (lds > (size_t)vits::kLdsBytesMax - 1024) return VITS_E_UNSUPPORTED;
-  auto kern = conv1d_flat_kernel<T, NT, WM>;
+  auto kern = conv1d_flat_kernel<T, NT, WM, WR>;
   // once per kernel instance, to the hardware maximum: a per-launch value would be whatever the LAST call set by
   // the time a captured graph replays its nodes
   static bool lds_attr_set = false;
@@ -291,6 +304,9 @@ int conv1d_flat_dispatch(const vits_conv_desc& d, int t_out, hipStream_t s) {
   if (d.k > KMAX) return VITS_E_UNSUPPORTED;
   const long rows = (long)d.b * t_out;
   if (d.dtype == VITS_DT_BF16) {
+    static const int big = getenv("VITS_FLAT_BIG") ? atoi(getenv("VITS_FLAT_BIG")) : 0;       // measured: the 64x64-per-wave variant is
+    // SLOWER for the step (53.2 vs 52.1 ms): these layers are bound by load latency at 2 workgroups per CU, not by LDS reads
+    if (d.c_out > 64 && big == 2 && rows >= 2048) return launch_flat<__bf16, 2, 2, 2>(d, t_out, s);                // 128 x 128, 64 x 64 per wave
     if (d.c_out > 64 && rows * ((d.c_out + 127) / 128) >= 128 * 512) return launch_flat<__bf16, 4, 4>(d, t_out, s);   // 128 x 128
     if (d.c_out > 64) return launch_flat<__bf16, 2, 2>(d, t_out, s);                                               // 64 x 128
     if (d.c_out > 32) return launch_flat<__bf16, 1, 2>(d, t_out, s);                                               // 64 x 64

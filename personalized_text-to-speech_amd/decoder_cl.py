@@ -163,6 +163,7 @@ class DecoderFn(torch.autograd.Function):
         saved = list(ctx.saved_tensors)
         R = ctx.R
         grads = [None] * len(R)
+        defer = K.DeferredReductions(dy.device)      # every slab reduction of this backward in one launch (or a few) at the end
 
         def flip_t(r):                       # data-gradient operand of weight slot r
             return WA.bwd_operand(R[r])
@@ -172,7 +173,7 @@ class DecoderFn(torch.autograd.Function):
             if bias_slot is not None:
                 db = torch.empty(dy.size(2), dtype=torch.float32, device=dy.device)
                 grads[bias_slot] = db
-            return WG(x, dy, k, out=R[slot].dw, dbias=db, **kw)
+            return WG(x, dy, k, out=R[slot].dw, dbias=db, defer=defer, **kw)
 
         def bias_grad(d):
             return K.colsum(d if d.is_contiguous() else d.contiguous())
@@ -229,6 +230,7 @@ class DecoderFn(torch.autograd.Function):
         grads[i_pre[0]] = WGo(z, dh, 7, i_pre[0], i_pre[1], pad=3)
         dz = C(dh, flip_t(i_pre[0]), None, pad=3)
         dcond = K.colsum(dh if dh.is_contiguous() else dh.contiguous(), per_item=True) if ctx.has_cond else None
+        defer.flush()
         return (None, None, dz, dcond, *grads)
 
 

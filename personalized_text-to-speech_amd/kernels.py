@@ -281,6 +281,43 @@ def workspace(nbytes, device):
     return buf
 
 
+class DeferredReductions:
+    """Collects the second stages of a group of weight-gradient launches (vits_conv1d_cl_wgrad_deferred) and runs them as ONE
+    launch (vits_wgrad_reduce_pending).  Each deferred call gets its own slice of a per-stream slab buffer; when the buffer is
+    full the pending reductions are flushed early.  Used by the fused layer nodes, whose weight gradients are only consumed
+    after their backward returns."""
+    CAPACITY = 1 << 30
+    _buffers = {}
+
+    def __init__(self, device):
+        self.device, self.pending, self.off = device, [], 0
+
+    def _buffer(self):
+        key = (self.device, torch.cuda.current_stream(self.device).cuda_stream)
+        buf = DeferredReductions._buffers.get(key)
+        if buf is None:
+            buf = DeferredReductions._buffers[key] = torch.empty(self.CAPACITY, dtype=torch.uint8, device=self.device)
+        return buf
+
+    def alloc(self, nbytes):
+        nbytes = (nbytes + 255) & ~255
+        if nbytes > self.CAPACITY:
+            return None                                   # caller falls back to the immediate form
+        if self.off + nbytes > self.CAPACITY:
+            self.flush()
+        view = self._buffer()[self.off:self.off + nbytes]
+        self.off += nbytes
+        return view
+
+    def flush(self):
+        if self.pending:
+            arr = (_lib.WgradPending * len(self.pending))(*self.pending)
+            import ctypes
+            rc = _lib.lib().vits_wgrad_reduce_pending(ctypes.addressof(arr), len(self.pending), _lib.stream_ptr())
+            _lib.check(rc, "vits_wgrad_reduce_pending")
+        self.pending, self.off = [], 0
+
+
 _counters = {}
 # Measured: correct (bitwise equal to the two-launch result, tests/test_conv_gpu.py) but 3x SLOWER for the whole step: the
 # agent-scope release/acquire fences the hand-off needs write back / invalidate a whole XCD's L2 on gfx950, once per
@@ -298,7 +335,7 @@ def tile_counters(device):
     return buf
 
 
-def conv1d_cl_wgrad_raw(x, dy, k, lengths=None, dil=1, pad=0, stride=1, in_slope=1.0, flags=0, out=None, dbias=None, groups=1):
+def conv1d_cl_wgrad_raw(x, dy, k, lengths=None, dil=1, pad=0, stride=1, in_slope=1.0, flags=0, out=None, dbias=None, groups=1, defer=None):
     """dW [k, c_out, c_in] float32 of conv1d_cl_raw(x, w, ...) given dy [b, t_out, c_out]; optionally the bias
     gradient (column sums of dy) into `dbias` float32 [c_out] in the same launch."""
     _lib.require_cuda(x, dy)
@@ -314,7 +351,9 @@ def conv1d_cl_wgrad_raw(x, dy, k, lengths=None, dil=1, pad=0, stride=1, in_slope
     assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (k, c_out, c_in_w)
     L = _lib.lib()
     ws_bytes = L.vits_conv1d_cl_wgrad_workspace(b, t_out, c_in_w, c_out, k)
-    ws = workspace(ws_bytes, x.device)
+    ws = defer.alloc(ws_bytes) if defer is not None else None          # deferred second stage: a slice of its own
+    if ws is None:
+        defer, ws = None, workspace(ws_bytes, x.device)
     d = _lib.WgradDesc(dtype=_DT[x.dtype], b=b, t=t, c_in=c_in, c_out=c_out, k=k, dil=dil, pad=pad, stride=stride, flags=int(flags),
                        ldx=_rows(x, "x"), lddy=_rows(dy, "dy"), in_slope=float(in_slope), groups=groups,
                        x=x.data_ptr(), dy=dy.data_ptr(), dw=out.data_ptr(), workspace=ws.data_ptr(), workspace_bytes=ws.numel(),
@@ -326,7 +365,13 @@ def conv1d_cl_wgrad_raw(x, dy, k, lengths=None, dil=1, pad=0, stride=1, in_slope
     assert dbias is None or (dbias.dtype == torch.float32 and dbias.is_contiguous() and dbias.numel() == c_out)
     import ctypes
     e0 = _lib.timer.start("vits_conv1d_cl_wgrad")
-    rc = L.vits_conv1d_cl_wgrad(ctypes.addressof(d), _lib.stream_ptr())
+    if defer is not None:
+        pend = _lib.WgradPending()
+        rc = L.vits_conv1d_cl_wgrad_deferred(ctypes.addressof(d), _lib.stream_ptr(), ctypes.addressof(pend))
+        if rc == 0 and pend.splits > 0:
+            defer.pending.append(pend)
+    else:
+        rc = L.vits_conv1d_cl_wgrad(ctypes.addressof(d), _lib.stream_ptr())
     if e0 is not None:
         es = x.element_size()
         _lib.timer.stop("vits_conv1d_cl_wgrad", e0, (2.0 * b * t_out * c_out * c_in_w * k,

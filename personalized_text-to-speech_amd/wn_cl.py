@@ -194,6 +194,7 @@ class WNFn(torch.autograd.Function):
         torch.mul(d_out, rowmask, out=dcat[..., H:]) if d_out.dtype == dtype else dcat[..., H:].copy_(d_out * rowmask)   # d(output * x_mask)
         d_h, d_o = dcat[..., :H], dcat[..., H:]
         dcond = [] if ctx.has_cond else None
+        defer = K.DeferredReductions(d_out.device)      # the 2L slab reductions of this stack run as one launch at the end
         for i in reversed(range(L)):
             acts, pre, h = saved.pop(), saved.pop(), saved.pop()
             r_in, r_rs = R[4 * i], R[4 * i + 2]
@@ -202,16 +203,17 @@ class WNFn(torch.autograd.Function):
             last = i == L - 1
             dy_rs = d_o if last else dcat
             db_rs = torch.empty(H if last else 2 * H, dtype=torch.float32, device=d_out.device)
-            grads[4 * i + 2] = WG(acts, dy_rs, 1, out=r_rs.dw, dbias=db_rs)
+            grads[4 * i + 2] = WG(acts, dy_rs, 1, out=r_rs.dw, dbias=db_rs, defer=defer)
             grads[4 * i + 3] = db_rs
             d_pre = C(dy_rs, WA.bwd_operand(r_rs), None, mg_src=pre, lengths=lengths, flags=K.CONV_GATE_BWD | K.CONV_MASK_OUT, gate_h=H)
             db_in = torch.empty(2 * H, dtype=torch.float32, device=d_out.device)
-            grads[4 * i] = WG(h, d_pre, k, dil=d, pad=pad, out=r_in.dw, dbias=db_in)
+            grads[4 * i] = WG(h, d_pre, k, dil=d, pad=pad, out=r_in.dw, dbias=db_in, defer=defer)
             grads[4 * i + 1] = db_in
             if dcond is not None:
                 dcond.append(K.colsum(d_pre, per_item=True))              # [b, 2H]: gradient of cond[i]
             C(d_pre, WA.bwd_operand(r_in), None, res=None if last else d_h, out=d_h, lengths=lengths, dil=d, pad=pad,
               flags=K.CONV_MASK_OUT | (0 if last else K.CONV_RES_AFTER))
+        defer.flush()
         dc = torch.stack(dcond[::-1], 0) if dcond is not None else None
         return (None, None, d_h.contiguous(), None, dc, *grads)
 

@@ -193,6 +193,7 @@ def test_flat_row_kernel_and_strided_data_gradient(pkg, dtype, tol):
     K = pkg.kernels
     torch.manual_seed(5)
     for (b, t, ci, co, kk, st, pd) in [(48, 57, 32, 128, 5, 3, 2), (33, 19, 128, 512, 5, 3, 2), (80, 7, 1024, 1024, 5, 1, 2),
+                                       (64, 51, 256, 320, 5, 1, 2), (96, 102, 128, 512, 5, 3, 2),      # >= 2048 rows: 64x64-per-wave variant
                                        (16, 40, 64, 32, 3, 1, 1), (5, 301, 32, 96, 41, 4, 20)]:
         x = torch.randn(b, t, ci, device=DEV).to(dtype)
         w = (torch.randn(kk, co, ci, device=DEV) / (ci * kk) ** 0.5).to(dtype)
