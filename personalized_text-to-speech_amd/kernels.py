@@ -283,39 +283,50 @@ def workspace(nbytes, device):
 
 class DeferredReductions:
     """Collects the second stages of a group of weight-gradient launches (vits_conv1d_cl_wgrad_deferred) and runs them as ONE
-    launch (vits_wgrad_reduce_pending).  Each deferred call gets its own slice of a per-stream slab buffer; when the buffer is
-    full the pending reductions are flushed early.  Used by the fused layer nodes, whose weight gradients are only consumed
-    after their backward returns."""
+    launch (vits_wgrad_reduce_pending).  Each deferred call gets its own slice of a per-stream slab buffer shared by all
+    collectors (bump allocation; the space is recycled when no collector has anything pending); when the buffer is full the
+    collector flushes early or the call falls back to the immediate form.  Used by the fused layer nodes and by the weight
+    arena, whose weight gradients are only consumed after their backward returns."""
     CAPACITY = 1 << 30
-    _buffers = {}
+    _state = {}                  # (device, stream) -> [buffer, bump offset, pending entries of all collectors]
 
     def __init__(self, device):
-        self.device, self.pending, self.off = device, [], 0
+        self.device, self.pending = device, []
 
-    def _buffer(self):
+    def _st(self):
         key = (self.device, torch.cuda.current_stream(self.device).cuda_stream)
-        buf = DeferredReductions._buffers.get(key)
-        if buf is None:
-            buf = DeferredReductions._buffers[key] = torch.empty(self.CAPACITY, dtype=torch.uint8, device=self.device)
-        return buf
+        st = DeferredReductions._state.get(key)
+        if st is None:
+            st = DeferredReductions._state[key] = [torch.empty(self.CAPACITY, dtype=torch.uint8, device=self.device), 0, 0]
+        return st
 
     def alloc(self, nbytes):
         nbytes = (nbytes + 255) & ~255
-        if nbytes > self.CAPACITY:
-            return None                                   # caller falls back to the immediate form
-        if self.off + nbytes > self.CAPACITY:
+        st = self._st()
+        if st[1] + nbytes > self.CAPACITY:
             self.flush()
-        view = self._buffer()[self.off:self.off + nbytes]
-        self.off += nbytes
+        if st[1] + nbytes > self.CAPACITY:
+            return None                                   # caller falls back to the immediate form
+        view = st[0][st[1]:st[1] + nbytes]
+        st[1] += nbytes
         return view
 
+    def add(self, pend):
+        self.pending.append(pend)
+        self._st()[2] += 1
+
     def flush(self):
-        if self.pending:
-            arr = (_lib.WgradPending * len(self.pending))(*self.pending)
-            import ctypes
-            rc = _lib.lib().vits_wgrad_reduce_pending(ctypes.addressof(arr), len(self.pending), _lib.stream_ptr())
-            _lib.check(rc, "vits_wgrad_reduce_pending")
-        self.pending, self.off = [], 0
+        if not self.pending:
+            return
+        import ctypes
+        st = self._st()
+        arr = (_lib.WgradPending * len(self.pending))(*self.pending)
+        rc = _lib.lib().vits_wgrad_reduce_pending(ctypes.addressof(arr), len(self.pending), _lib.stream_ptr())
+        _lib.check(rc, "vits_wgrad_reduce_pending")
+        st[2] -= len(self.pending)
+        self.pending = []
+        if st[2] <= 0:
+            st[1], st[2] = 0, 0
 
 
 _counters = {}
@@ -369,7 +380,7 @@ def conv1d_cl_wgrad_raw(x, dy, k, lengths=None, dil=1, pad=0, stride=1, in_slope
         pend = _lib.WgradPending()
         rc = L.vits_conv1d_cl_wgrad_deferred(ctypes.addressof(d), _lib.stream_ptr(), ctypes.addressof(pend))
         if rc == 0 and pend.splits > 0:
-            defer.pending.append(pend)
+            defer.add(pend)
     else:
         rc = L.vits_conv1d_cl_wgrad(ctypes.addressof(d), _lib.stream_ptr())
     if e0 is not None:

@@ -106,6 +106,14 @@ class WeightArena:
         for i, h in enumerate(self.handles):
             _registry[h.data_ptr()] = (self, i)
 
+    @property
+    def defer(self):
+        d = self.__dict__.get("_defer")
+        if d is None and self.w_fwd.is_cuda:
+            from . import kernels
+            d = self.__dict__["_defer"] = kernels.DeferredReductions(self.w_fwd.device)
+        return d
+
     def stale(self):
         return any(p.data_ptr() != q for p, q in zip(self.params, self.ptrs))
 
@@ -116,6 +124,8 @@ class WeightArena:
 class PrepFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, arena, *params):
+        if arena.defer is not None:
+            arena.defer.flush()                      # leftovers of a backward that never reached this node
         rc = _lib.lib().vits_weight_prep(arena.table.data_ptr(), arena.n, arena.total_rows, _DT[arena.dtype],
                                          arena.w_fwd.data_ptr(), arena.w_bwd.data_ptr(), _lib.stream_ptr())
         _lib.check(rc, "vits_weight_prep")
@@ -125,6 +135,8 @@ class PrepFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *dws):
         arena = ctx.arena
+        if arena.defer is not None:
+            arena.defer.flush()                      # the deferred second stages of this network's weight-gradient launches
         for i, d in enumerate(dws):
             if d is None:
                 arena.dws[i].zero_()
@@ -139,11 +151,12 @@ class PrepFn(torch.autograd.Function):
 
 
 class Resolved:
-    """What a layer node needs for one convolution weight."""
-    __slots__ = ("fwd", "bwd", "dw")
+    """What a layer node needs for one convolution weight (`defer`: the arena's collector of weight-gradient second stages,
+    run in one launch right before the arena maps the weight gradients back to parameter gradients)."""
+    __slots__ = ("fwd", "bwd", "dw", "defer")
 
-    def __init__(self, fwd, bwd, dw):
-        self.fwd, self.bwd, self.dw = fwd, bwd, dw
+    def __init__(self, fwd, bwd, dw, defer=None):
+        self.fwd, self.bwd, self.dw, self.defer = fwd, bwd, dw, defer
 
 
 _constants = {}            # data_ptr -> Resolved, for constant operands registered with register_constant()
@@ -164,7 +177,7 @@ def resolve(w, dtype):
     hit = _registry.get(w.data_ptr())
     if hit is not None and hit[0].dtype == dtype and tuple(w.shape) == tuple(hit[0].handles[hit[1]].shape):
         a, i = hit
-        return Resolved(a.fwd[i], a.bwd[i], a.dws[i])
+        return Resolved(a.fwd[i], a.bwd[i], a.dws[i], a.defer)
     wd = w.detach().to(dtype)
     return Resolved(wd, None, None)
 

@@ -76,7 +76,8 @@ class ConvCLFn(torch.autograd.Function):
             if want_db and dy.size(2) % 8 == 0:
                 db = torch.empty(dy.size(2), dtype=torch.float32, device=dy.device)
             dw = K.conv1d_cl_wgrad_raw(xd, dy, k, lengths=ctx.lengths, dil=dil, pad=pad, stride=stride, in_slope=in_slope,
-                                       flags=K.CONV_MASK_IN if mask_in else 0, out=R.dw, dbias=db, groups=ctx.groups)
+                                       flags=K.CONV_MASK_IN if mask_in else 0, out=R.dw, dbias=db, groups=ctx.groups,
+                                       defer=R.defer if R.dw is not None else None)
         if want_db and db is None:
             db = K.colsum(dy)
         dx = None
