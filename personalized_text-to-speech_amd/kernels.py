@@ -25,7 +25,8 @@ BACKENDS = {
     "layer_norm+gelu, depthwise conv": "hip",             # rowops.hip
     "relative-position attention": "hip",  # attn_softmax.hip + batched products on conv1d_cl
     "rational_quadratic_spline (+autograd)": "hip",       # rq_spline.hip
-    "element-wise glue, losses, embeddings, mel matmul": "rocm",   # PyTorch-ROCm device ops
+    "feature-matching / KL / duration sums, bias + conditioning column sums": "hip",   # reduce.hip
+    "element-wise glue, adversarial loss arithmetic, embedding lookups, mel matmul": "rocm",   # PyTorch-ROCm device ops
     "adamw": "rocm",                      # torch.optim.AdamW(fused=True, capturable=True)
 }
 
