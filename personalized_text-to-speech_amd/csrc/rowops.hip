@@ -181,6 +181,30 @@ __global__ __launch_bounds__(1024) void reduce_partials(const float* __restrict_
   }
 }
 
+// Two outputs in one launch: partial rows are [nA | nB] wide; blocks [0, ceil(nA/64)) reduce into outA, the others into outB.
+__global__ __launch_bounds__(1024) void reduce_partials2(const float* __restrict__ part, float* __restrict__ outA, int nA,
+                                                         float* __restrict__ outB, int nB, int W, int stride, int accumulate) {
+  __shared__ float sm[16][64];
+  const int blocksA = (nA + 63) / 64;
+  const bool isB = (int)blockIdx.x >= blocksA;
+  const int col = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int j = (isB ? (int)blockIdx.x - blocksA : (int)blockIdx.x) * 64 + col;
+  const int n = isB ? nB : nA;
+  const float* src = part + (isB ? nA : 0);
+  float* out = isB ? outB : outA;
+  float s = 0.f;
+  if (j < n)
+    for (int w = slice; w < W; w += 16) s += src[(size_t)w * stride + j];
+  sm[slice][col] = s;
+  __syncthreads();
+  if (slice == 0 && j < n) {
+    float t = accumulate ? out[j] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sm[k][col];
+    out[j] = t;
+  }
+}
+
 // ---------------------------------------------------------------- depth-wise conv
 template <typename T>
 __global__ void dwconv_fwd(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
@@ -289,8 +313,7 @@ extern "C" int vits_ln_act_cl_bwd(int dtype, const void* x, const float* gamma, 
     hipLaunchKernelGGL(ln_act_bwd<float>, dim3(wgs), dim3(threads), lds, s, (const float*)x, gamma, beta, (const float*)dy, (float*)dx, part, rows, c, eps, act, rpw);
   else return VITS_E_UNSUPPORTED;
   // partials are [wg][2][c]: dgamma then dbeta
-  hipLaunchKernelGGL(reduce_partials, dim3((c + 63) / 64), dim3(1024), 0, s, part, dgamma, c, wgs, 2 * c, accumulate);
-  hipLaunchKernelGGL(reduce_partials, dim3((c + 63) / 64), dim3(1024), 0, s, part + c, dbeta, c, wgs, 2 * c, accumulate);
+  hipLaunchKernelGGL(reduce_partials2, dim3(2 * ((c + 63) / 64)), dim3(1024), 0, s, part, dgamma, c, dbeta, c, wgs, 2 * c, accumulate);
   return vits::check_launch("vits_ln_act_cl_bwd");
 }
 
@@ -324,7 +347,6 @@ extern "C" int vits_dwconv_cl_bwd(int dtype, const void* x, const float* w, cons
     hipLaunchKernelGGL(dwconv_bwd<float>, dim3(wgs), dim3(threads), 0, s, (const float*)x, w, lengths, (const float*)dy, (float*)dx, part, b, t, c, k, dil, rpw);
   else return VITS_E_UNSUPPORTED;
   // partial rows are [(k+1)*c]: first k*c = dw[c][k], then c = dbias
-  hipLaunchKernelGGL(reduce_partials, dim3((k * c + 63) / 64), dim3(1024), 0, s, part, dw, k * c, wgs, (k + 1) * c, accumulate);
-  hipLaunchKernelGGL(reduce_partials, dim3((c + 63) / 64), dim3(1024), 0, s, part + (size_t)k * c, dbias, c, wgs, (k + 1) * c, accumulate);
+  hipLaunchKernelGGL(reduce_partials2, dim3((k * c + 63) / 64 + (c + 63) / 64), dim3(1024), 0, s, part, dw, k * c, dbias, c, wgs, (k + 1) * c, accumulate);
   return vits::check_launch("vits_dwconv_cl_bwd");
 }

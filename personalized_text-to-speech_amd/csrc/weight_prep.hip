@@ -69,14 +69,24 @@ __global__ __launch_bounds__(256) void prep_fwd(const vits_prep_entry* __restric
     ss = block_sum(ss, red);
     scale = e.g[e.row_lo + r] / sqrtf(ss);
   }
+  if (e.layout == 0 || e.layout == 3) {
+    // tap-major walk: consecutive threads write consecutive input channels of one tap (coalesced rows of w_fwd); the reads of
+    // the small source row are strided by k but stay in cache
+    const int cin_row = inner / e.k;                               // input channels stored in this row (c_in, or c_in/groups)
+    const int ci_base = e.layout == 3 ? (r / (e.c_out / e.groups)) * cin_row : 0;
+    for (int j = threadIdx.x; j < inner; j += blockDim.x) {
+      const int tap = j / cin_row, cl = j - tap * cin_row, ci = ci_base + cl;
+      const float val = v[cl * e.k + tap] * scale;
+      put<T>(w_fwd, e.off + ((size_t)tap * e.c_out_p + r) * e.c_in_p + ci, val);
+      put<T>(w_bwd, e.off + ((size_t)(e.k - 1 - tap) * e.c_in_p + ci) * e.c_out_p + r, val);
+    }
+    return;
+  }
   for (int i = threadIdx.x; i < inner; i += blockDim.x) {
     const Idx x = locate(e, r, i);
     const float val = v[i] * scale;
     if (e.layout == 2) {                  // torch layout kept (consumer is a MIOpen convolution): only weight-norm + dtype
       put<T>(w_fwd, e.off + (size_t)r * inner + i, val);
-    } else if (e.layout == 0 || e.layout == 3) {
-      put<T>(w_fwd, e.off + ((size_t)x.tap * e.c_out_p + x.co) * e.c_in_p + x.ci, val);
-      put<T>(w_bwd, e.off + ((size_t)(e.k - 1 - x.tap) * e.c_in_p + x.ci) * e.c_out_p + x.co, val);
     } else {
       const size_t col = (size_t)x.tap * e.c_out + x.co;                   // column of the 1x1 operand
       put<T>(w_fwd, e.off + col * e.c_in_p + x.ci, val);                   // [1][k*c_out][c_in_p]
@@ -100,17 +110,21 @@ __global__ __launch_bounds__(256) void prep_bwd(const vits_prep_entry* __restric
     if (e.layout == 0) return dw[e.off + ((size_t)x.tap * e.c_out_p + x.co) * e.c_in_p + x.ci];
     return dw[e.off + ((size_t)x.tap * e.c_out + x.co) * e.c_in_p + x.ci];
   };
+  // layouts 0 / 3: walk the row tap-major so that consecutive threads read consecutive input channels of dw (coalesced)
+  const bool tapmajor = e.layout == 0 || e.layout == 3;
+  const int cin_row = inner / e.k;
+  auto src_index = [&](int j) -> int { return tapmajor ? (j % cin_row) * e.k + j / cin_row : j; };
   if (!e.g) {
-    for (int i = threadIdx.x; i < inner; i += blockDim.x) dv[i] = dw_at(i);
+    for (int j = threadIdx.x; j < inner; j += blockDim.x) { const int i = src_index(j); dv[i] = dw_at(i); }
     return;
   }
   float ss = 0.f, dot = 0.f;
-  for (int i = threadIdx.x; i < inner; i += blockDim.x) { const float a = v[i]; ss += a * a; dot += a * dw_at(i); }
+  for (int j = threadIdx.x; j < inner; j += blockDim.x) { const int i = src_index(j); const float a = v[i]; ss += a * a; dot += a * dw_at(i); }
   ss = block_sum(ss, red);
   dot = block_sum(dot, red);
   const float norm = sqrtf(ss), gval = e.g[e.row_lo + r];
   const float s = gval / norm, c = dot / ss;
-  for (int i = threadIdx.x; i < inner; i += blockDim.x) dv[i] = s * (dw_at(i) - v[i] * c);
+  for (int j = threadIdx.x; j < inner; j += blockDim.x) { const int i = src_index(j); dv[i] = s * (dw_at(i) - v[i] * c); }
   if (threadIdx.x == 0) dparam[e.off_dg + e.row_lo + r] = dot / norm;
 }
 
