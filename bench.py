@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--fp32", action="store_true", help="parity mode: no bf16 autocast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--segmented", action="store_true", help="force the three-graph (data-parallel) form of the captured step at N = 1")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying the captured hipGraph")
     args = ap.parse_args()
 
@@ -107,13 +108,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    use_graph = (world == 1) and not args.eager
-    if use_graph:
-        tuner.capture(batch, warmup=3)
+    use_graph = not args.eager
+    if use_graph and world == 1:
+        (tuner.capture_segments if args.segmented else tuner.capture)(batch, warmup=3)
         tuner.verify_replay()                            # same state -> same result, and agrees with the eager step
-        step = tuner.replay
-    else:
-        step = lambda: tuner.step(batch)
+    elif use_graph:
+        # N > 1: three graphs cut where the ranks exchange gradients, RCCL all-reduce between the replays.  All ranks must
+        # agree that capture and verification succeeded; otherwise every rank falls back to eager launches (and says so).
+        ok = 1
+        try:
+            tuner.capture_segments(batch, warmup=3)
+            tuner.verify_replay()
+        except Exception as e:                            # noqa: BLE001 - reported, then a collective decision
+            print(f"[bench rank {rank}] captured step unavailable ({type(e).__name__}: {e}); falling back to eager launches",
+                  file=sys.stderr, flush=True)
+            ok = 0
+        flag = torch.tensor([ok], device=device, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag) == 0:
+            use_graph = False
+            tuner._graph = None
+            tuner.buckets_d.manual(False); tuner.buckets_g.manual(False)
+    step = tuner.replay if use_graph else (lambda: tuner.step(batch))
     trace = os.environ.get("VITS_BENCH_TRACE") == "1"      # debugging aid: sync + log every step
     for i in range(args.warmup):
         out = step()
@@ -179,7 +195,7 @@ def main():
                     data="synthetic",
                     config=dict(workload=f"{args.workload}: {cfg_name}.json, per-rank batch {batch_size}, T_y<= {T_y} frames, "
                                          f"T_x<= {T_x} tokens, segment {hps.train.segment_size} samples, fwd+bwd+AdamW (G and D)",
-                                parallelism=f"dp{world}", execution="hipGraph replay" if use_graph else "eager launches",
+                                parallelism=f"dp{world}", execution=("hipGraph replay" if world == 1 and not args.segmented else "three hipGraphs, gradient all-reduce between them") if use_graph else "eager launches",
                                 kernels=P.kernels.BACKENDS, losses=losses),
                     roofline=roof)
         if world == 1 and not args.no_cpu_baseline:

@@ -58,6 +58,7 @@ class GradBuckets:
         self._work = []
         self._launched = [False] * len(self.buckets)
         self._enabled = True
+        self._manual = False
 
     def _close(self, plist):
         n = sum(p.numel() for p in plist)
@@ -96,8 +97,34 @@ class GradBuckets:
         else:
             self._work.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat))
 
+    # ---- manual mode (captured step): no hooks; pack() inside the graph, all_reduce() eagerly between graph replays
+    def manual(self, flag):
+        self._manual = flag
+
+    def pack(self):
+        """Copy every bucket's gradients into its flat buffer (one multi-tensor copy each) and point param.grad at the flat
+        views; graph-capturable (no collective)."""
+        for flat, plist, views in self.buckets:
+            have = [(v, p.grad) for v, p in zip(views, plist) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
+            missing = [v for v, p in zip(views, plist) if p.grad is None]
+            if missing:
+                torch._foreach_zero_(missing)
+            if have:
+                torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+            for v, p in zip(views, plist):
+                p.grad = v
+
+    def all_reduce(self):
+        """Blocking (stream-ordered) average of every flat bucket over the ranks."""
+        for flat, _, _ in self.buckets:
+            if dist.get_backend(self.group) == "nccl":
+                dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
+            else:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+                flat.div_(self.world)
+
     def _on_grad(self, p):
-        if not self._enabled:
+        if not self._enabled or self._manual:
             return
         i = self._bucket_of[p]
         self._pending[i] -= 1
@@ -106,6 +133,8 @@ class GradBuckets:
 
     def finish(self):
         """Launch whatever did not complete (parameters without a gradient this step) and wait."""
+        if self._manual:
+            return
         for i in range(len(self.buckets)):
             self._launch(i)
         for w in self._work:

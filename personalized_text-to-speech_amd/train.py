@@ -52,7 +52,21 @@ class FineTuner:
         return contextlib.nullcontext()
 
     def step(self, batch):
-        """batch = (x, x_lengths, spec, spec_lengths, y, y_lengths, speakers), already on the device."""
+        """batch = (x, x_lengths, spec, spec_lengths, y, y_lengths, speakers), already on the device.
+        Three phases separated by the two points where data-parallel ranks must have exchanged gradients."""
+        manual = self.buckets_d._manual                      # an eager step next to a captured one exchanges gradients the eager way
+        self.buckets_d.manual(False); self.buckets_g.manual(False)
+        try:
+            self._phase_a(batch)
+            self.buckets_d.finish()
+            self._phase_b()
+            self.buckets_g.finish()
+            return self._phase_c()
+        finally:
+            self.buckets_d.manual(manual); self.buckets_g.manual(manual)
+
+    def _phase_a(self, batch):
+        """Generator forward, mel targets, discriminator forward on (y, y_hat.detach()) and the backward of its loss."""
         hps = self.hps
         x, x_lengths, spec, spec_lengths, y, y_lengths, speakers = batch
         seg_frames = hps.train.segment_size // hps.data.hop_length
@@ -73,21 +87,24 @@ class FineTuner:
         loss_disc, losses_disc_r, losses_disc_g = discriminator_loss(y_d_hat_r, y_d_hat_g)
         self.buckets_d.zero_grad()
         loss_disc.backward()
-        self.buckets_d.finish()
-        grad_norm_d = commons.grad_norm_l2(self.net_d.parameters())
-        self.optim_d.step()
+        self._st = dict(y=y, y_hat=y_hat, l_length=l_length, y_mel=y_mel, y_hat_mel=y_hat_mel, z_p=z_p, logs_q=logs_q, m_p=m_p,
+                        logs_p=logs_p, z_mask=z_mask, loss_disc=loss_disc.detach())
 
-        # ---- generator step (finetune_speaker_v2.py:216-232); D already updated (its fmaps come
-        #      from the new weights, as in the reference) and frozen for this backward
+    def _phase_b(self):
+        """Discriminator update, then the generator losses against the UPDATED discriminator and their backward
+        (finetune_speaker_v2.py:216-232); D is frozen for this backward."""
+        hps, st = self.hps, self._st
+        st["grad_norm_d"] = commons.grad_norm_l2(self.net_d.parameters())
+        self.optim_d.step()
         for p in self.net_d.parameters():
             p.requires_grad_(False)
         self.buckets_d.enabled(False)
         try:
             with self._autocast():
-                y_d_hat_r, y_d_hat_g, fmap_r, fmap_g = self.net_d(y, y_hat)
-            loss_dur = torch.sum(l_length.float())
-            loss_mel = F.l1_loss(y_mel.float(), y_hat_mel.float()) * hps.train.c_mel
-            loss_kl = kl_loss(z_p, logs_q, m_p, logs_p, z_mask) * hps.train.c_kl
+                y_d_hat_r, y_d_hat_g, fmap_r, fmap_g = self.net_d(st["y"], st["y_hat"])
+            loss_dur = torch.sum(st["l_length"].float())
+            loss_mel = F.l1_loss(st["y_mel"].float(), st["y_hat_mel"].float()) * hps.train.c_mel
+            loss_kl = kl_loss(st["z_p"], st["logs_q"], st["m_p"], st["logs_p"], st["z_mask"]) * hps.train.c_kl
             loss_fm = feature_loss(fmap_r, fmap_g)
             loss_gen, losses_gen = generator_loss(y_d_hat_g)
             loss_gen_all = loss_gen + loss_fm + loss_mel + loss_dur + loss_kl
@@ -97,13 +114,15 @@ class FineTuner:
             for p in self.net_d.parameters():
                 p.requires_grad_(True)
             self.buckets_d.enabled(True)
-        self.buckets_g.finish()
-        grad_norm_g = commons.grad_norm_l2(self.net_g.parameters())
-        self.optim_g.step()
+        self._out = dict(loss_disc=st["loss_disc"], loss_gen=loss_gen.detach(), loss_fm=loss_fm.detach(), loss_mel=loss_mel.detach(),
+                         loss_dur=loss_dur.detach(), loss_kl=loss_kl.detach(), grad_norm_d=st["grad_norm_d"])
+        self._st = None
 
-        return dict(loss_disc=loss_disc.detach(), loss_gen=loss_gen.detach(), loss_fm=loss_fm.detach(),
-                    loss_mel=loss_mel.detach(), loss_dur=loss_dur.detach(), loss_kl=loss_kl.detach(),
-                    grad_norm_d=grad_norm_d, grad_norm_g=grad_norm_g)
+    def _phase_c(self):
+        out = self._out
+        out["grad_norm_g"] = commons.grad_norm_l2(self.net_g.parameters())
+        self.optim_g.step()
+        return out
 
     # ---------------------------------------------------------------------------------------------
     # hipGraph execution of the step (single GPU): the step is thousands of small kernels and is
@@ -128,6 +147,37 @@ class FineTuner:
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
             self._static_out = self.step(batch)
+        _lib.timer.enabled = timer_was
+        return self._static_out
+
+    def capture_segments(self, batch, warmup=3):
+        """Data-parallel form of capture(): the step as THREE graphs sharing one memory pool, cut at the two points where
+        ranks exchange gradients.  Each graph ends by packing its network's gradients into the flat buckets; the bucket
+        all-reduces run eagerly between the replays (RCCL is not captured), then the next graph reads the reduced
+        gradients from the same flat views."""
+        from . import _lib
+        assert self.device.type == "cuda" and self._graph is None
+        timer_was, _lib.timer.enabled = _lib.timer.enabled, False
+        self._static_batch = batch
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.step(batch)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.buckets_d.manual(True)
+        self.buckets_g.manual(True)
+        ga, gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga):
+            self._phase_a(batch)
+            self.buckets_d.pack()
+        with torch.cuda.graph(gb, pool=ga.pool()):
+            self._phase_b()
+            self.buckets_g.pack()
+        with torch.cuda.graph(gc, pool=ga.pool()):
+            self._static_out = self._phase_c()
+        self._graph = (ga, gb, gc)
         _lib.timer.enabled = timer_was
         return self._static_out
 
@@ -180,7 +230,15 @@ class FineTuner:
             dst.copy_(src, non_blocking=True)
 
     def replay(self):
-        self._graph.replay()
+        if isinstance(self._graph, tuple):
+            ga, gb, gc = self._graph
+            ga.replay()
+            self.buckets_d.all_reduce()
+            gb.replay()
+            self.buckets_g.all_reduce()
+            gc.replay()
+        else:
+            self._graph.replay()
         return self._static_out
 
     def epoch_end(self):

@@ -52,6 +52,16 @@ def _worker(rank, world, port, out):
             g.div_(world)
         ref.append(gs)
     ok = all(torch.allclose(a, b, atol=1e-6) for s in range(2) for a, b in zip(res[s], ref[s]))
+    # manual mode (the captured, three-graph step): hooks off, pack() then all_reduce() give the same averages
+    buckets.manual(True)
+    buckets.zero_grad()
+    net(x).pow(2).mean().backward()
+    buckets.finish()                                   # a no-op in manual mode
+    buckets.pack()
+    buckets.all_reduce()
+    ok &= all(torch.allclose(p.grad, b, atol=1e-6) for p, b in zip(net.parameters(), ref[0]))
+    ok &= float(unused.grad.abs().sum()) == 0.0
+    buckets.manual(False)
     same_params = True
     for p in net.parameters():
         t = p.data.clone()
