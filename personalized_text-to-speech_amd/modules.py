@@ -35,6 +35,12 @@ class Conv1d(nn.Module):
         self.bias = nn.Parameter(proto.bias.data) if bias else None
 
     def forward(self, x):
+        if x.is_cuda and x.size(-1) == 1 and self.kernel_size == 1 and self.groups == 1 and self.in_channels % 4 == 0:
+            # one-frame conditioning vectors (speaker embedding -> per-item bias): an exact-fp32 product on this library's kernel
+            # (deterministic; the library convolution picked different algorithms from call to call)
+            from . import wn_cl
+            y = wn_cl.conv_cl(x.float().reshape(x.size(0), 1, x.size(1)), wn_cl.weight_of(self), self.bias, dtype=torch.float32)
+            return y.reshape(x.size(0), -1, 1)
         return K.conv1d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
 
 
