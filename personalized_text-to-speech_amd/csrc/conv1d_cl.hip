@@ -37,7 +37,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 
 constexpr int ROWB = 128;          // bytes of input channels staged per chunk
-constexpr int PITCH = ROWB + 16;   // LDS row pitch
+// LDS row pitch = ROWB * NC + 16 (PITCHK inside the kernel)
 constexpr int kThreads = 256;
 
 template <typename T> struct Elem;
@@ -74,16 +74,23 @@ constexpr int XV_MAX = 6;     // 16-byte vectors of the X tile a thread may hold
 constexpr int WV_MAX = 9;     // ... of the W slab (G*TN*8 <= 256*WV_MAX)
 
 // WM waves along time x WN = 4/WM waves along output channels; each wave owns 32 rows x 32*NT columns.
-template <typename T, int NT, int WM>
+// NC = 128-byte channel chunks staged per pipeline stage.  NC = 3 (bf16: 192 channels) makes the 1x1 layers of the WaveNet
+// stacks, the text encoder and the duration predictor SINGLE-stage: one round of global loads, then all the MFMAs — these
+// launches are bound by the load latency of their 3 sequential stages, not by bandwidth or math.
+template <typename T, int NT, int WM, int NC>
 __global__ __launch_bounds__(kThreads) void conv1d_cl_kernel(ConvArgs args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const vits_conv_desc& a = args.d;
   constexpr int V = Elem<T>::VEC;
-  constexpr int KC = Elem<T>::KC;
+  constexpr int KC = Elem<T>::KC * NC;    // channels per stage
+  constexpr int VPR = 8 * NC;             // 16-byte vectors per staged row
+  constexpr int PITCHK = ROWB * NC + 16;  // LDS row pitch (same bank pattern for NC = 1 and 3: 36 and 100 dwords, both 4 mod 32)
   constexpr int WN = 4 / WM;
   constexpr int TMW = 32 * WM;            // time rows per workgroup
   constexpr int TNW = 32 * NT;            // columns per wave
   constexpr int TN = TNW * WN;            // columns per workgroup
+  constexpr int XV = NC == 1 ? XV_MAX : (TMW * VPR) / kThreads + 1;      // NC > 1: k = 1, stride 1, so the X tile is exactly TMW rows
+  constexpr int WV = NC == 1 ? WV_MAX : (TN * VPR + kThreads - 1) / kThreads;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -98,7 +105,7 @@ __global__ __launch_bounds__(kThreads) void conv1d_cl_kernel(ConvArgs args) {
   const int co0 = blockIdx.y * (gate ? TN / 2 : TN);
   const int xrows = (TMW - 1) * a.stride + (a.k - 1) * a.dil + 1;
   unsigned char* ldsX = smem;
-  unsigned char* ldsW = smem + (size_t)xrows * PITCH;
+  unsigned char* ldsW = smem + (size_t)xrows * PITCHK;
 
   const T* X = static_cast<const T*>(a.x) + (size_t)b * a.t * a.ldx;
   const T* W = static_cast<const T*>(a.w) + (size_t)b * a.w_batch_stride;     // per-item operand (attention products) or shared weights
@@ -123,17 +130,17 @@ __global__ __launch_bounds__(kThreads) void conv1d_cl_kernel(ConvArgs args) {
   const int n_groups = (a.k + args.G - 1) / args.G;
   const int n_chunks = (a.c_in + KC - 1) / KC;
   const int n_stages = n_groups * n_chunks;
-  const int xvec = xrows * 8;
-  const bool x_in_regs = xvec <= kThreads * XV_MAX;        // else: stage X synchronously (long strided tiles)
+  const int xvec = xrows * VPR;
+  const bool x_in_regs = xvec <= kThreads * XV;        // else: stage X synchronously (long strided tiles)
 
-  u32x4 xr[XV_MAX], wr[WV_MAX];
+  u32x4 xr[XV], wr[WV];
   auto load_x = [&](int ci0) {
 #pragma unroll
-    for (int i = 0; i < XV_MAX; ++i) {
+    for (int i = 0; i < XV; ++i) {
       const int idx = tid + i * kThreads;
       u32x4 v = {0u, 0u, 0u, 0u};
       if (idx < xvec) {
-        const int row = idx >> 3, ch = idx & 7;
+        const int row = idx / VPR, ch = idx % VPR;
         const int t = t0 * a.stride - a.pad + row, ci = ci0 + ch * V;
         if (t >= 0 && t < t_in_hi && ci < a.c_in) {
           v = *reinterpret_cast<const u32x4*>(X + (size_t)t * a.ldx + ci);
@@ -145,31 +152,31 @@ __global__ __launch_bounds__(kThreads) void conv1d_cl_kernel(ConvArgs args) {
   };
   auto store_x = [&]() {
 #pragma unroll
-    for (int i = 0; i < XV_MAX; ++i) {
+    for (int i = 0; i < XV; ++i) {
       const int idx = tid + i * kThreads;
-      if (idx < xvec) *reinterpret_cast<u32x4*>(ldsX + (idx >> 3) * PITCH + (idx & 7) * 16) = xr[i];
+      if (idx < xvec) *reinterpret_cast<u32x4*>(ldsX + (idx / VPR) * PITCHK + (idx % VPR) * 16) = xr[i];
     }
   };
   auto stage_x_direct = [&](int ci0) {
     for (int idx = tid; idx < xvec; idx += kThreads) {
-      const int row = idx >> 3, ch = idx & 7;
+      const int row = idx / VPR, ch = idx % VPR;
       const int t = t0 * a.stride - a.pad + row, ci = ci0 + ch * V;
       u32x4 v = {0u, 0u, 0u, 0u};
       if (t >= 0 && t < t_in_hi && ci < a.c_in) {
         v = *reinterpret_cast<const u32x4*>(X + (size_t)t * a.ldx + ci);
         if (a.in_slope != 1.0f) v = lrelu_vec<T>(v, a.in_slope);
       }
-      *reinterpret_cast<u32x4*>(ldsX + row * PITCH + ch * 16) = v;
+      *reinterpret_cast<u32x4*>(ldsX + row * PITCHK + ch * 16) = v;
     }
   };
   auto load_w = [&](int ci0, int tg) {
     const int ntap = (a.k - tg < args.G) ? (a.k - tg) : args.G;
 #pragma unroll
-    for (int i = 0; i < WV_MAX; ++i) {
+    for (int i = 0; i < WV; ++i) {
       const int idx = tid + i * kThreads;
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (idx < ntap * TN * 8) {
-        const int ch = idx & 7, col = (idx >> 3) % TN, tl = (idx >> 3) / TN;
+      if (idx < ntap * TN * VPR) {
+        const int ch = idx % VPR, col = (idx / VPR) % TN, tl = (idx / VPR) / TN;
         const int co = col_to_co(col), ci = ci0 + ch * V;
         if (co >= 0 && ci < a.c_in) v = *reinterpret_cast<const u32x4*>(W + ((size_t)(tg + tl) * a.c_out + co) * a.ldw + ci);
       }
@@ -179,9 +186,9 @@ __global__ __launch_bounds__(kThreads) void conv1d_cl_kernel(ConvArgs args) {
   auto store_w = [&](int tg) {
     const int ntap = (a.k - tg < args.G) ? (a.k - tg) : args.G;
 #pragma unroll
-    for (int i = 0; i < WV_MAX; ++i) {
+    for (int i = 0; i < WV; ++i) {
       const int idx = tid + i * kThreads;
-      if (idx < ntap * TN * 8) *reinterpret_cast<u32x4*>(ldsW + (idx >> 3) * PITCH + (idx & 7) * 16) = wr[i];
+      if (idx < ntap * TN * VPR) *reinterpret_cast<u32x4*>(ldsW + (idx / VPR) * PITCHK + (idx % VPR) * 16) = wr[i];
     }
   };
 
@@ -201,14 +208,14 @@ __global__ __launch_bounds__(kThreads) void conv1d_cl_kernel(ConvArgs args) {
     }
     const int ntap = (a.k - tg < args.G) ? (a.k - tg) : args.G;
     for (int tl = 0; tl < ntap; ++tl) {
-      const unsigned char* xa = ldsX + ((wm * 32 + r) * a.stride + (tg + tl) * a.dil) * PITCH + 16 * h;
-      const unsigned char* wb = ldsW + (tl * TN + wn * TNW + r) * PITCH + 16 * h;
+      const unsigned char* xa = ldsX + ((wm * 32 + r) * a.stride + (tg + tl) * a.dil) * PITCHK + 16 * h;
+      const unsigned char* wb = ldsW + (tl * TN + wn * TNW + r) * PITCHK + 16 * h;
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
+      for (int m = 0; m < 4 * NC; ++m) {
         const u32x4 av = *reinterpret_cast<const u32x4*>(xa + 32 * m);
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-          const u32x4 bv = *reinterpret_cast<const u32x4*>(wb + n * 32 * PITCH + 32 * m);
+          const u32x4 bv = *reinterpret_cast<const u32x4*>(wb + n * 32 * PITCHK + 32 * m);
           if constexpr (sizeof(T) == 2) {
             union { u32x4 u; bf16x8 v; } ua, ub;
             ua.u = av; ub.u = bv;
@@ -299,18 +306,19 @@ __global__ __launch_bounds__(kThreads) void conv1d_cl_kernel(ConvArgs args) {
   }
 }
 
-template <typename T, int NT, int WM>
+template <typename T, int NT, int WM, int NC = 1>
 int launch_conv(const vits_conv_desc& d, int t_out, hipStream_t s) {
   ConvArgs args{d, t_out, 1};
   constexpr int WN = 4 / WM, TMW = 32 * WM, TN = 32 * NT * WN;
+  constexpr int PITCHK = ROWB * NC + 16;
   const int xrows = (TMW - 1) * d.stride + (d.k - 1) * d.dil + 1;
   int G = (kThreads * WV_MAX) / (TN * 8);        // taps per W stage: what one prefetch round can hold (<= 41 KB)
-  if (G < 1) G = 1;
+  if (G < 1 || NC > 1) G = 1;
   if (G > d.k) G = d.k;
   args.G = G;
-  const size_t lds = (size_t)xrows * PITCH + (size_t)G * TN * PITCH;
+  const size_t lds = (size_t)xrows * PITCHK + (size_t)G * TN * PITCHK;
   if (lds > (size_t)vits::kLdsBytesMax) return VITS_E_UNSUPPORTED;
-  auto kern = conv1d_cl_kernel<T, NT, WM>;
+  auto kern = conv1d_cl_kernel<T, NT, WM, NC>;
   // once per kernel instance, to the hardware maximum: a per-launch value would be whatever the LAST call set by
   // the time a captured graph replays its nodes
   static bool lds_attr_set = false;
@@ -337,6 +345,17 @@ int dispatch_tile(const vits_conv_desc& d, int t_out, hipStream_t s) {
   if (gate) {                                    // needs an even number of tiles per wave
     if (wgs(128, 128) >= want || cols <= 64) return launch_conv<T, 4, 4>(d, t_out, s);
     return launch_conv<T, 2, 2>(d, t_out, s);    // 64 rows x (2 waves x 64 columns)
+  }
+  if constexpr (sizeof(T) == 2) {
+    // single-stage form for the 1x1 layers with 65..192 input channels (see the kernel's NC): 64-row tiles keep the LDS
+    // footprint at (64 + TN) * 400 B, i.e. two or more workgroups per CU
+    // measured: correct (tests pass with it on) but the step is SLOWER (50.9 vs 49.7 ms): fewer tile shapes and ~200 VGPRs cost
+    // more than the two saved load round trips; opt-in for further experiments
+    static const bool wide = getenv("VITS_CONV_WIDE") && getenv("VITS_CONV_WIDE")[0] == '1';
+    if (wide && d.k == 1 && d.stride == 1 && d.c_in > 64 && d.c_in <= 192) {
+      if (cols > 64) return launch_conv<T, 2, 2, 3>(d, t_out, s);     // 64 x 128
+      if (cols > 32) return launch_conv<T, 1, 2, 3>(d, t_out, s);     // 64 x 64
+    }
   }
   if (cols > 64 && wgs(128, 128) >= want) return launch_conv<T, 4, 4>(d, t_out, s);
   if (cols > 64 && wgs(64, 128) >= want) return launch_conv<T, 2, 2>(d, t_out, s);
