@@ -308,6 +308,11 @@ int conv1d_flat_dispatch(const vits_conv_desc& d, int t_out, hipStream_t s) {
     // SLOWER for the step (53.2 vs 52.1 ms): these layers are bound by load latency at 2 workgroups per CU, not by LDS reads
     if (d.c_out > 64 && big == 2 && rows >= 2048) return launch_flat<__bf16, 2, 2, 2>(d, t_out, s);                // 128 x 128, 64 x 64 per wave
     if (d.c_out > 64 && rows * ((d.c_out + 127) / 128) >= 128 * 512) return launch_flat<__bf16, 4, 4>(d, t_out, s);   // 128 x 128
+    // 64 x 64 tiles when 64 x 128 would leave CUs idle, and for grouped layers (one 64-channel chunk per tile, 41 taps: more
+    // taps per stage and twice the workgroups)
+    static const bool small = !(getenv("VITS_FLAT_SMALL") && getenv("VITS_FLAT_SMALL")[0] == '0');
+    const long wgs_64x128 = ((rows + 63) / 64) * ((d.c_out + 127) / 128);
+    if (d.c_out > 64 && small && (d.groups > 1 || wgs_64x128 < 320)) return launch_flat<__bf16, 1, 2>(d, t_out, s);
     if (d.c_out > 64) return launch_flat<__bf16, 2, 2>(d, t_out, s);                                               // 64 x 128
     if (d.c_out > 32) return launch_flat<__bf16, 1, 2>(d, t_out, s);                                               // 64 x 64
     return launch_flat<__bf16, 1, 4>(d, t_out, s);                                                                 // 128 x 32
