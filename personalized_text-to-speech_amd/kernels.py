@@ -3,9 +3,10 @@
 Each op is either
   * HIP  — a hand-written gfx950 kernel reached through the C ABI of libvitsmi.so (include/vitsmi.h),
            wrapped in a torch.autograd.Function where it needs a backward; or
-  * ROCm — a composition of PyTorch-ROCm device ops (MIOpen / rocBLAS), for ops whose HIP kernel has
-           not landed yet.  DESIGN.md §kernels lists which is which; `BACKENDS` below is the same
-           table in code, and bench.py prints it.
+  * ROCm — a composition of PyTorch-ROCm device ops (element-wise glue, rocBLAS for two small matmuls, the fused
+           AdamW).  DESIGN.md §4 lists which is which; `BACKENDS` below is the same table in code, and bench.py
+           prints it.  The library convolutions behind `conv1d` / `conv_transpose1d` here are only reached by the
+           A/B switches (VITS_DISC_P / VITS_DISC_S = library) and by generic module calls outside the hot path.
 There is no CPU implementation of the HIP ops: they raise on non-GPU tensors.
 """
 import math

@@ -280,8 +280,12 @@ class Generator(nn.Module):
         y = decoder_cl.DecoderFn.apply(self._plan, dtype, x.transpose(1, 2), cond, *decoder_cl.prepared_weights(self))
         return y[..., 0].unsqueeze(1).float()
 
-    def remove_weight_norm(self):
-        raise NotImplementedError("weight-norm folding for inference is SURVEY §8 (f-2), not built yet")
+    def remove_weight_norm(self):                              # models.py:291-296
+        print('Removing weight norm...')
+        for l in self.ups:
+            modules.remove_weight_norm(l)
+        for l in self.resblocks:
+            l.remove_weight_norm()
 
 
 def _first_layer_fp32(layer, x):

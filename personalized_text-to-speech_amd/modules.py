@@ -44,6 +44,18 @@ class Conv1d(nn.Module):
         return K.conv1d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
 
 
+def remove_weight_norm(module):
+    """torch.nn.utils.remove_weight_norm for the WN* modules below (reference models.py:291-296, modules.py:178-184,225-229,
+    254-256): g * v / ||v|| is folded into a plain `weight` parameter; afterwards state_dict holds `weight` instead of
+    `weight_g` / `weight_v`, exactly like the reference's modules after the call, and the kernels take the plain weight."""
+    if "weight_g" not in module._parameters:
+        raise ValueError(f"weight_norm of 'weight' not found in {module}")
+    w = K.weight_norm(module.weight_v, module.weight_g).detach().clone()
+    del module._parameters["weight_g"], module._parameters["weight_v"]
+    module._parameters["weight"] = nn.Parameter(w)          # (the class attribute `weight` is a property that returns it)
+    return module
+
+
 class WNConv1d(nn.Module):
     """weight_norm(Conv1d): parameters `bias`, `weight_g`, `weight_v`."""
 
@@ -59,6 +71,9 @@ class WNConv1d(nn.Module):
 
     @property
     def weight(self):
+        plain = self._parameters.get("weight")              # after remove_weight_norm()
+        if plain is not None:
+            return plain
         from . import weight_arena
         h = weight_arena.handle_for(self, "torch")          # inside a scope: prepared by the multi-tensor kernel
         return h if h is not None else K.weight_norm(self.weight_v, self.weight_g)
@@ -82,7 +97,8 @@ class WNConvTranspose1d(nn.Module):
 
     @property
     def weight(self):
-        return K.weight_norm(self.weight_v, self.weight_g)
+        plain = self._parameters.get("weight")              # after remove_weight_norm()
+        return plain if plain is not None else K.weight_norm(self.weight_v, self.weight_g)
 
     def forward(self, x):
         return K.conv_transpose1d(x, self.weight, self.bias, self.stride, self.padding)
@@ -187,6 +203,12 @@ class WN(nn.Module):
         out = wn_cl.wn_forward_cl(self, x.transpose(1, 2).contiguous(), wn_cl.lengths_of(x_mask), g)
         return out.transpose(1, 2).to(x.dtype)
 
+    def remove_weight_norm(self):                              # modules.py:178-184
+        if self.gin_channels != 0:
+            remove_weight_norm(self.cond_layer)
+        for l in list(self.in_layers) + list(self.res_skip_layers):
+            remove_weight_norm(l)
+
 
 class ResBlock1(nn.Module):
     # modules.py:187-229
@@ -214,6 +236,10 @@ class ResBlock1(nn.Module):
             x = x * x_mask
         return x
 
+    def remove_weight_norm(self):                              # modules.py:225-229
+        for l in list(self.convs1) + list(self.convs2):
+            remove_weight_norm(l)
+
 
 class ResBlock2(nn.Module):
     # modules.py:232-256
@@ -233,6 +259,10 @@ class ResBlock2(nn.Module):
         if x_mask is not None:
             x = x * x_mask
         return x
+
+    def remove_weight_norm(self):                              # modules.py:254-256
+        for l in self.convs:
+            remove_weight_norm(l)
 
 
 class Log(nn.Module):

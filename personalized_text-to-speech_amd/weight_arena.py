@@ -115,7 +115,10 @@ class WeightArena:
         return d
 
     def stale(self):
-        return any(p.data_ptr() != q for p, q in zip(self.params, self.ptrs))
+        """Parameters re-allocated (e.g. .to(device)) or replaced (remove_weight_norm folds weight_g / weight_v into `weight`)."""
+        if any(p.data_ptr() != q for p, q in zip(self.params, self.ptrs)):
+            return True
+        return any((s.g is not None) != ("weight_g" in s.module._parameters) for s in self.specs)
 
     def prepare(self):
         return PrepFn.apply(self, *self.params)

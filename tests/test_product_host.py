@@ -84,3 +84,28 @@ def test_noise_replay_guards(pkg):
     with pytest.raises(RuntimeError, match="never consumed"):
         with n.replay([torch.zeros(1)]):
             pass
+
+
+def test_remove_weight_norm_folds_parameters_like_the_reference(pkg):
+    """After remove_weight_norm() (reference models.py:291-296, modules.py:178-184) the modules own a plain `weight`
+    equal to g * v / ||v|| and state_dict carries `weight` instead of `weight_g` / `weight_v`."""
+    torch.manual_seed(0)
+    m = pkg.modules
+    rb = m.ResBlock1(8, 3, (1, 3, 5))
+    before = [c.weight.detach().clone() for c in list(rb.convs1) + list(rb.convs2)]
+    assert "convs1.0.weight_g" in rb.state_dict()
+    rb.remove_weight_norm()
+    sd = rb.state_dict()
+    assert "convs1.0.weight" in sd and "convs1.0.weight_g" not in sd and "convs1.0.weight_v" not in sd
+    for c, w in zip(list(rb.convs1) + list(rb.convs2), before):
+        assert isinstance(c.weight, torch.nn.Parameter) and torch.equal(c.weight, w)
+    wn = m.WN(8, 5, 1, 3, gin_channels=4)
+    w_in = wn.in_layers[1].weight.detach().clone()
+    wn.remove_weight_norm()
+    assert torch.equal(wn.in_layers[1].weight, w_in) and "cond_layer.weight" in wn.state_dict()
+    up = m.WNConvTranspose1d(8, 4, 4, 2, 1)
+    w_up = up.weight.detach().clone()
+    m.remove_weight_norm(up)
+    assert torch.equal(up.weight, w_up)
+    with pytest.raises(ValueError):
+        m.remove_weight_norm(up)
