@@ -148,10 +148,15 @@ __global__ __launch_bounds__(kThreads) void conv1d_flat_kernel(FlatArgs args) {
         const int tap = taplist[g0 + tl];
         const int num = xs_t[i] * a.stride + tap * a.dil - a.pad;
         const int ci = ci0 + ch * V;
-        if (num >= 0 && (num % in_div) == 0 && ci < a.c_in) {
-          const int ti = num / in_div;
-          const int len = a.lengths ? a.lengths[xs_b[i]] : a.t;
-          const int hi = (a.flags & VITS_CONV_MASK_IN) ? (len < a.t ? len : a.t) : a.t;
+        int ti = num;
+        bool on_grid = true;
+        if (in_div > 1) {                    // (uniform branch: keeps the integer division out of the common case)
+          ti = num / in_div;
+          on_grid = ti * in_div == num;
+        }
+        if (num >= 0 && on_grid && ci < a.c_in) {
+          int hi = a.t;
+          if (a.flags & VITS_CONV_MASK_IN) { const int len = a.lengths[xs_b[i]]; hi = len < a.t ? len : a.t; }
           if (ti < hi) {
             v = *reinterpret_cast<const u32x4*>(X + ((size_t)xs_b[i] * a.t + ti) * a.ldx + ci);
             if (a.in_slope != 1.0f) v = lrelu_vec<T>(v, a.in_slope);
