@@ -35,6 +35,7 @@ struct WgradArgs {
   float in_slope;
   int flags;
   int ldx, lddy, stride;
+  float inv_tout;         // 1 / Tout
   int groups;             // > 1: block-diagonal only, compact dw [k][c_out][c_in/groups]
   int* counters;          // non-null: the last split to finish a tile sums the slabs itself (fixed order), see below
   float* dw_final; float* db_final; int accumulate;
@@ -123,7 +124,9 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
     if constexpr (FLAT) {                    // t0 = first flat row of the chunk; X = base of the whole tensor
       const int kk = row / TK, m = t0 + (row - kk * TK);
       if (m >= a.B * a.Tout) return v;
-      const int b = m / a.Tout;
+      int b = (int)((float)m * a.inv_tout);            // m / Tout without the integer-division sequence (m < 2^24: exact after the fix-up)
+      if (b * a.Tout > m) --b;
+      if ((b + 1) * a.Tout <= m) ++b;
       t = (m - b * a.Tout) * a.stride + (tap0 + kk) * a.dil - a.pad;
       if (a.flags & VITS_CONV_MASK_IN) { const int len = a.lengths[b]; t_in_hi = len < a.T ? len : a.T; }
       X += (size_t)b * a.T * a.ldx;
@@ -515,7 +518,7 @@ static int wgrad_impl(const vits_wgrad_desc* desc, void* stream, vits_wgrad_pend
   const size_t tiles = (size_t)vits::ceil_div(d.c_out, CT) * (d.groups > 1 ? 1 : vits::ceil_div(d.c_in, CT)) * vits::ceil_div(d.k, kt);
   const bool fused = !direct && d.counters != nullptr && d.counters_len >= tiles;
   WgradArgs a{d.x, d.dy, direct ? d.dw : ws, d.lengths, d.b, d.t, t_out, d.c_in, d.c_out, d.k, d.dil, d.pad,
-              S, vits::ceil_div(t_out, TK), d.in_slope, d.flags, d.ldx, d.lddy, d.stride, d.groups,
+              S, vits::ceil_div(t_out, TK), d.in_slope, d.flags, d.ldx, d.lddy, d.stride, 1.0f / (float)t_out, d.groups,
               fused ? d.counters : nullptr, d.dw, d.dbias, accumulate ? 1 : 0,
               d.dbias ? (direct ? d.dbias : ws + n) : nullptr, direct ? 0 : n + nb};
   hipStream_t s = static_cast<hipStream_t>(stream);
