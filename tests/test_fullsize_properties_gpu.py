@@ -114,3 +114,27 @@ def test_remove_weight_norm_keeps_inference_outputs(pkg):
     with torch.no_grad(), pkg.rng.noise.replay([noise0]):
         b = g.voice_conversion(spec, lens, src, tgt)[0]
     assert a.shape == b.shape and float((a - b).abs().max() / a.abs().max()) < 1e-5
+
+
+def test_long_prompt_inference_is_consistent(pkg, net):
+    """BASELINE config C4 shape (513-token prompts = 256 phonemes + blanks; reduced to 4 items): infer() returns a waveform of
+    hop * frames samples, a hard monotonic alignment with exactly one token per valid frame, all finite (models.py:499-520)."""
+    g, hps = net
+    torch.manual_seed(6)
+    b, t_x = 4, 513
+    x = torch.randint(1, hps.n_symbols, (b, t_x), device=DEV)
+    x[:, 0::2] = 0                                               # interspersed blanks (commons.py:24-27)
+    x_lengths = torch.tensor([513, 401, 257, 129], device=DEV)
+    sid = torch.arange(b, device=DEV) % g.n_speakers
+    with torch.no_grad():
+        o, attn, y_mask, _ = g.infer(x, x_lengths, sid=sid, noise_scale=0.667, length_scale=1.0, noise_scale_w=0.8, max_len=1200)
+    frames = y_mask.size(-1)
+    assert o.shape == (b, 1, frames * hps.data.hop_length) and bool(torch.isfinite(o).all())
+    a = attn[:, 0]                                               # [b, t_y, t_x]
+    valid = y_mask[:, 0]
+    assert torch.equal(a.sum(2), valid)                          # one token per valid frame, none beyond
+    idx = a.argmax(2)
+    for i in range(b):
+        n = int(valid[i].sum())
+        steps = idx[i, 1:n] - idx[i, : n - 1]
+        assert n > 0 and bool((steps >= 0).all())                # monotonic
