@@ -42,7 +42,7 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 
 // One WAVE per row (lane l owns channels l, l+64, ...: up to 16 per lane), 4 rows per workgroup step: the
 // row statistics are wave shuffles, no workgroup barrier inside the row loop.
-constexpr int NCMAX = 16;
+constexpr int kNcMax = 16;      // up to 1024 channels; the kernels are instantiated for 4 (<= 256 channels) and 16 column slots per lane
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -50,7 +50,7 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-template <typename T>
+template <typename T, int NCMAX>
 __global__ __launch_bounds__(256) void ln_act_fwd(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                            const T* __restrict__ res, T* __restrict__ y, int rows, int C, float eps, int act, int rows_per_wg) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void ln_act_fwd(const T* __restrict__ x, const
   }
 }
 
-template <typename T>
+template <typename T, int NCMAX>
 __global__ __launch_bounds__(256) void ln_act_bwd(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                            const T* __restrict__ dy, T* __restrict__ dx, float* __restrict__ part, int rows, int C, float eps,
                            int act, int rows_per_wg) {
@@ -290,9 +290,11 @@ extern "C" int vits_ln_act_cl(int dtype, const void* x, const float* gamma, cons
   const int threads = 256, rpw = pick_rows_per_wg(rows, 1024), wgs = (rows + rpw - 1) / rpw;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == VITS_DT_BF16)
-    hipLaunchKernelGGL(ln_act_fwd<__bf16>, dim3(wgs), dim3(threads), 0, s, (const __bf16*)x, gamma, beta, (const __bf16*)res, (__bf16*)y, rows, c, eps, act, rpw);
+    if (c <= 256) hipLaunchKernelGGL((ln_act_fwd<__bf16, 4>), dim3(wgs), dim3(threads), 0, s, (const __bf16*)x, gamma, beta, (const __bf16*)res, (__bf16*)y, rows, c, eps, act, rpw);
+    else hipLaunchKernelGGL((ln_act_fwd<__bf16, kNcMax>), dim3(wgs), dim3(threads), 0, s, (const __bf16*)x, gamma, beta, (const __bf16*)res, (__bf16*)y, rows, c, eps, act, rpw);
   else if (dtype == VITS_DT_F32)
-    hipLaunchKernelGGL(ln_act_fwd<float>, dim3(wgs), dim3(threads), 0, s, (const float*)x, gamma, beta, (const float*)res, (float*)y, rows, c, eps, act, rpw);
+    if (c <= 256) hipLaunchKernelGGL((ln_act_fwd<float, 4>), dim3(wgs), dim3(threads), 0, s, (const float*)x, gamma, beta, (const float*)res, (float*)y, rows, c, eps, act, rpw);
+    else hipLaunchKernelGGL((ln_act_fwd<float, kNcMax>), dim3(wgs), dim3(threads), 0, s, (const float*)x, gamma, beta, (const float*)res, (float*)y, rows, c, eps, act, rpw);
   else return VITS_E_UNSUPPORTED;
   return vits::check_launch("vits_ln_act_cl");
 }
@@ -308,9 +310,11 @@ extern "C" int vits_ln_act_cl_bwd(int dtype, const void* x, const float* gamma, 
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* part = static_cast<float*>(workspace);
   if (dtype == VITS_DT_BF16)
-    hipLaunchKernelGGL(ln_act_bwd<__bf16>, dim3(wgs), dim3(threads), lds, s, (const __bf16*)x, gamma, beta, (const __bf16*)dy, (__bf16*)dx, part, rows, c, eps, act, rpw);
+    if (c <= 256) hipLaunchKernelGGL((ln_act_bwd<__bf16, 4>), dim3(wgs), dim3(threads), lds, s, (const __bf16*)x, gamma, beta, (const __bf16*)dy, (__bf16*)dx, part, rows, c, eps, act, rpw);
+    else hipLaunchKernelGGL((ln_act_bwd<__bf16, kNcMax>), dim3(wgs), dim3(threads), lds, s, (const __bf16*)x, gamma, beta, (const __bf16*)dy, (__bf16*)dx, part, rows, c, eps, act, rpw);
   else if (dtype == VITS_DT_F32)
-    hipLaunchKernelGGL(ln_act_bwd<float>, dim3(wgs), dim3(threads), lds, s, (const float*)x, gamma, beta, (const float*)dy, (float*)dx, part, rows, c, eps, act, rpw);
+    if (c <= 256) hipLaunchKernelGGL((ln_act_bwd<float, 4>), dim3(wgs), dim3(threads), lds, s, (const float*)x, gamma, beta, (const float*)dy, (float*)dx, part, rows, c, eps, act, rpw);
+    else hipLaunchKernelGGL((ln_act_bwd<float, kNcMax>), dim3(wgs), dim3(threads), lds, s, (const float*)x, gamma, beta, (const float*)dy, (float*)dx, part, rows, c, eps, act, rpw);
   else return VITS_E_UNSUPPORTED;
   // partials are [wg][2][c]: dgamma then dbeta
   hipLaunchKernelGGL(reduce_partials2, dim3(2 * ((c + 63) / 64)), dim3(1024), 0, s, part, dgamma, c, dbeta, c, wgs, 2 * c, accumulate);
