@@ -221,6 +221,13 @@ typedef struct vits_prep_entry {
   int32_t layout, c_out, c_in, k, c_out_p, c_in_p, row_lo, n_rows, row0, groups;
 } vits_prep_entry;
 
+/* Layout 4 = layout 0 whose tap-reversed transposed operand w_bwd is NOT written by vits_weight_prep (a strided 2-byte scatter)
+ * but by vits_weight_prep_transpose afterwards: an LDS transpose of the 64 x 64 tiles of w_fwd listed in `tiles`
+ * (entry index, tap, first output channel, first input channel), coalesced on both sides. */
+typedef struct vits_prep_tile { int32_t entry, tap, co0, ci0; } vits_prep_tile;
+int vits_weight_prep_transpose(const vits_prep_tile* tiles, int n_tiles, const vits_prep_entry* entries, int dtype,
+                               const void* w_fwd, void* w_bwd, void* stream);
+
 int vits_weight_prep(const vits_prep_entry* entries, int n_entries, int total_rows, int dtype, void* w_fwd,
                      void* w_bwd, void* stream);
 int vits_weight_prep_bwd(const vits_prep_entry* entries, int n_entries, int total_rows, const float* dw,

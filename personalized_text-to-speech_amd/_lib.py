@@ -10,7 +10,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvitsmi.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 c_int = ctypes.c_int
 c_void_p = ctypes.c_void_p
@@ -33,6 +33,7 @@ SIGNATURES = {
     "vits_dwconv_cl": (c_int, [c_int] + [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
     "vits_dwconv_cl_bwd": (c_int, [c_int] + [c_void_p] * 8 + [c_size_t] + [c_int] * 6 + [c_void_p]),
     "vits_weight_prep": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "vits_weight_prep_transpose": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "vits_weight_prep_bwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "vits_convt_fold_cl": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "vits_convt_unfold_cl": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),

@@ -45,7 +45,7 @@ template <> __device__ __forceinline__ void put<__bf16>(__bf16* p, size_t i, flo
 struct Idx { int tap, co, ci; };
 __device__ __forceinline__ Idx locate(const vits_prep_entry& e, int r, int inner) {
   Idx x;
-  if (e.layout != 1) {            // Conv1d [c_out][c_in][k]: row = co (within the entry), inner = ci*k + tap
+  if (e.layout != 1) {            // Conv1d [c_out][c_in][k] (layouts 0, 2, 3, 4): row = co (within the entry), inner = ci*k + tap
     x.co = r; x.ci = inner / e.k; x.tap = inner % e.k;
     if (e.layout == 3) x.ci += (r / (e.c_out / e.groups)) * (e.c_in / e.groups);   // grouped: channel inside the dense operand
   } else {                        // ConvTranspose1d [c_in][c_out][k]: row = ci, inner = co*k + j
@@ -69,24 +69,15 @@ __global__ __launch_bounds__(256) void prep_fwd(const vits_prep_entry* __restric
     ss = block_sum(ss, red);
     scale = e.g[e.row_lo + r] / sqrtf(ss);
   }
-  if (e.layout == 0 || e.layout == 3) {
-    // tap-major walk: consecutive threads write consecutive input channels of one tap (coalesced rows of w_fwd); the reads of
-    // the small source row are strided by k but stay in cache
-    const int cin_row = inner / e.k;                               // input channels stored in this row (c_in, or c_in/groups)
-    const int ci_base = e.layout == 3 ? (r / (e.c_out / e.groups)) * cin_row : 0;
-    for (int j = threadIdx.x; j < inner; j += blockDim.x) {
-      const int tap = j / cin_row, cl = j - tap * cin_row, ci = ci_base + cl;
-      const float val = v[cl * e.k + tap] * scale;
-      put<T>(w_fwd, e.off + ((size_t)tap * e.c_out_p + r) * e.c_in_p + ci, val);
-      put<T>(w_bwd, e.off + ((size_t)(e.k - 1 - tap) * e.c_in_p + ci) * e.c_out_p + r, val);
-    }
-    return;
-  }
   for (int i = threadIdx.x; i < inner; i += blockDim.x) {
     const Idx x = locate(e, r, i);
     const float val = v[i] * scale;
     if (e.layout == 2) {                  // torch layout kept (consumer is a MIOpen convolution): only weight-norm + dtype
       put<T>(w_fwd, e.off + (size_t)r * inner + i, val);
+    } else if (e.layout == 0 || e.layout == 3 || e.layout == 4) {
+      put<T>(w_fwd, e.off + ((size_t)x.tap * e.c_out_p + x.co) * e.c_in_p + x.ci, val);
+      // the transposed copy: a strided 2-byte scatter from here; layout 4 leaves it to transpose_tiles (coalesced both ways)
+      if (e.layout != 4) put<T>(w_bwd, e.off + ((size_t)(e.k - 1 - x.tap) * e.c_in_p + x.ci) * e.c_out_p + x.co, val);
     } else {
       const size_t col = (size_t)x.tap * e.c_out + x.co;                   // column of the 1x1 operand
       put<T>(w_fwd, e.off + col * e.c_in_p + x.ci, val);                   // [1][k*c_out][c_in_p]
@@ -107,11 +98,10 @@ __global__ __launch_bounds__(256) void prep_bwd(const vits_prep_entry* __restric
     if (e.layout == 2) return dw[e.off + (size_t)r * inner + i];
     if (e.layout == 3) return dw[e.off + ((size_t)(i % e.k) * e.c_out + r) * (e.c_in / e.groups) + i / e.k];   // compact [k][c_out][Ig]
     const Idx x = locate(e, r, i);
-    if (e.layout == 0) return dw[e.off + ((size_t)x.tap * e.c_out_p + x.co) * e.c_in_p + x.ci];
+    if (e.layout == 0 || e.layout == 4) return dw[e.off + ((size_t)x.tap * e.c_out_p + x.co) * e.c_in_p + x.ci];
     return dw[e.off + ((size_t)x.tap * e.c_out + x.co) * e.c_in_p + x.ci];
   };
-  // layouts 0 / 3: walk the row tap-major so that consecutive threads read consecutive input channels of dw (coalesced)
-  const bool tapmajor = e.layout == 0 || e.layout == 3;
+  const bool tapmajor = false;          // measured: the tap-major walk makes the dv writes scattered and the kernel 1.7x slower
   const int cin_row = inner / e.k;
   auto src_index = [&](int j) -> int { return tapmajor ? (j % cin_row) * e.k + j / cin_row : j; };
   if (!e.g) {
@@ -128,7 +118,44 @@ __global__ __launch_bounds__(256) void prep_bwd(const vits_prep_entry* __restric
   if (threadIdx.x == 0) dparam[e.off_dg + e.row_lo + r] = dot / norm;
 }
 
+// w_bwd[k-1-tap][ci][co] = w_fwd[tap][co][ci] for 64 x 64 tiles listed in a table (layout-4 entries): LDS transpose, 128-byte
+// rows on both sides
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_tiles(const vits_prep_tile* __restrict__ tiles, const vits_prep_entry* __restrict__ ents,
+                                                       const T* __restrict__ w_fwd, T* __restrict__ w_bwd) {
+  __shared__ T tile[64][66];
+  const vits_prep_tile t = tiles[blockIdx.x];
+  const vits_prep_entry e = ents[t.entry];
+  const int c = threadIdx.x & 63, r4 = threadIdx.x >> 6;
+  const T* src = w_fwd + e.off + (size_t)t.tap * e.c_out_p * e.c_in_p;
+  T* dst = w_bwd + e.off + (size_t)(e.k - 1 - t.tap) * e.c_in_p * e.c_out_p;
+#pragma unroll 4
+  for (int r = r4; r < 64; r += 4) {
+    const int co = t.co0 + r, ci = t.ci0 + c;
+    tile[r][c] = (co < e.c_out_p && ci < e.c_in_p) ? src[(size_t)co * e.c_in_p + ci] : (T)0.f;
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int r = r4; r < 64; r += 4) {
+    const int ci = t.ci0 + r, co = t.co0 + c;
+    if (ci < e.c_in_p && co < e.c_out_p) dst[(size_t)ci * e.c_out_p + co] = tile[c][r];
+  }
+}
+
 }  // namespace
+
+extern "C" int vits_weight_prep_transpose(const vits_prep_tile* tiles, int n_tiles, const vits_prep_entry* entries, int dtype,
+                                          const void* w_fwd, void* w_bwd, void* stream) {
+  if (!tiles || n_tiles <= 0 || !entries || !w_fwd || !w_bwd) return VITS_E_BADARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == VITS_DT_BF16)
+    hipLaunchKernelGGL(transpose_tiles<__bf16>, dim3(n_tiles), dim3(256), 0, s, tiles, entries, static_cast<const __bf16*>(w_fwd), static_cast<__bf16*>(w_bwd));
+  else if (dtype == VITS_DT_F32)
+    hipLaunchKernelGGL(transpose_tiles<float>, dim3(n_tiles), dim3(256), 0, s, tiles, entries, static_cast<const float*>(w_fwd), static_cast<float*>(w_bwd));
+  else
+    return VITS_E_UNSUPPORTED;
+  return vits::check_launch("vits_weight_prep_transpose");
+}
 
 extern "C" int vits_weight_prep(const vits_prep_entry* entries, int n_entries, int total_rows, int dtype, void* w_fwd,
                                 void* w_bwd, void* stream) {

@@ -75,6 +75,7 @@ class WeightArena:
         self.dparam_views = [self.dparam[o:o + p.numel()].view_as(p) for o, p in zip(self.p_off, self.params)]
         # operand arenas
         offs, off, row0 = [], 0, 0
+        tiles = []
         ents = (_lib.PrepEntry * len(specs))()
         for i, s in enumerate(specs):
             offs.append(off)
@@ -82,13 +83,17 @@ class WeightArena:
             e.v, e.g = s.v.data_ptr(), (s.g.data_ptr() if s.g is not None else None)
             e.off, e.off_dv = off, self.p_off[pidx[id(s.v)]]
             e.off_dg = self.p_off[pidx[id(s.g)]] if s.g is not None else 0
-            e.layout, e.c_out, e.c_in, e.k = (3 if s.groups > 1 else (2 if s.torch_layout else (1 if s.transpose else 0))), s.c_out, s.c_in, s.k
+            e.layout, e.c_out, e.c_in, e.k = (3 if s.groups > 1 else (2 if s.torch_layout else (1 if s.transpose else 4))), s.c_out, s.c_in, s.k
+            if e.layout == 4:                                   # transposed operand by the tiled LDS transpose (coalesced)
+                tiles += [(i, tap, co0, ci0) for tap in range(s.k) for co0 in range(0, s.c_out_p, 64) for ci0 in range(0, s.c_in_p, 64)]
             e.groups = s.groups
             e.c_out_p, e.c_in_p, e.row_lo, e.n_rows, e.row0 = s.c_out_p, s.c_in_p, s.row_lo, s.n_rows, row0
             row0 += s.n_rows
             off += (s.numel + 63) & ~63                         # keep every operand 128-byte aligned
         self.total_rows, self.n = row0, len(specs)
         self.table = torch.frombuffer(bytearray(bytes(ents)), dtype=torch.uint8).to(dev)
+        self.n_tiles = len(tiles)
+        self.tiles = torch.tensor(tiles, dtype=torch.int32, device=dev) if tiles else None
         self.w_fwd = torch.zeros(off, dtype=dtype, device=dev)
         self.w_bwd = torch.zeros(off, dtype=dtype, device=dev)
         self.handle = self.w_fwd if dtype == torch.float32 else torch.empty(off, dtype=torch.float32, device=dev)
@@ -132,6 +137,10 @@ class PrepFn(torch.autograd.Function):
         rc = _lib.lib().vits_weight_prep(arena.table.data_ptr(), arena.n, arena.total_rows, _DT[arena.dtype],
                                          arena.w_fwd.data_ptr(), arena.w_bwd.data_ptr(), _lib.stream_ptr())
         _lib.check(rc, "vits_weight_prep")
+        if arena.n_tiles:
+            rc = _lib.lib().vits_weight_prep_transpose(arena.tiles.data_ptr(), arena.n_tiles, arena.table.data_ptr(), _DT[arena.dtype],
+                                                       arena.w_fwd.data_ptr(), arena.w_bwd.data_ptr(), _lib.stream_ptr())
+            _lib.check(rc, "vits_weight_prep_transpose")
         ctx.arena = arena
         return tuple(h.detach() for h in arena.handles)
 

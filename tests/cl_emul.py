@@ -226,6 +226,9 @@ class _FakeLib:
     def vits_weight_prep(self, table, n, rows, dtype, wf, wb, stream):
         weight_prep(self._arenas[wf]); return 0
 
+    def vits_weight_prep_transpose(self, tiles, n_tiles, table, dtype, wf, wb, stream):
+        return 0                                   # weight_prep() above already filled w_bwd
+
     def vits_weight_prep_bwd(self, table, n, rows, dw, dparam, stream):
         weight_prep_bwd(self._arenas[dw]); return 0
 
