@@ -192,12 +192,95 @@ __global__ __launch_bounds__(kThreads) void conv1d_cl_kernel(ConvArgs args) {
     }
   };
 
+  // one tap of the staged chunk: 4*NC k-steps of 32x32 MFMAs
+  auto mma_tap = [&](int tap_abs, int tl) {
+    const unsigned char* xa = ldsX + ((wm * 32 + r) * a.stride + tap_abs * a.dil) * PITCHK + 16 * h;
+    const unsigned char* wb = ldsW + (tl * TN + wn * TNW + r) * PITCHK + 16 * h;
+#pragma unroll
+    for (int m = 0; m < 4 * NC; ++m) {
+      const u32x4 av = *reinterpret_cast<const u32x4*>(xa + 32 * m);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const u32x4 bv = *reinterpret_cast<const u32x4*>(wb + n * 32 * PITCHK + 32 * m);
+        if constexpr (sizeof(T) == 2) {
+          union { u32x4 u; bf16x8 v; } ua, ub;
+          ua.u = av; ub.u = bv;
+          acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.v, ub.v, acc[n], 0, 0, 0);
+        } else {
+          union { u32x4 u; float f[4]; } ua, ub;
+          ua.u = av; ub.u = bv;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua.f[j], ub.f[j], acc[n], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  // ---- 1x1 layers with at most 3 channel chunks and a 64-row tile: ALL chunks' global loads are issued at once into the
+  // prefetch registers (the same registers the pipeline below uses), then staged and multiplied chunk by chunk — one load
+  // round trip instead of three for the ~430 small launches per step that are bound by exactly that latency.
+  constexpr int XS = TMW / 32, WS = TN / 32;                 // 16-byte vectors per thread per chunk (k = 1, stride 1: xrows = TMW)
+  constexpr bool CAN_PRELOAD = NC == 1 && 3 * XS <= XV && 3 * WS <= WV;
+  bool done = false;
+  if constexpr (CAN_PRELOAD) {
+    if (a.k == 1 && a.stride == 1 && n_chunks <= 3 && args.G == 1) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        if (c < n_chunks) {
+#pragma unroll
+          for (int j = 0; j < XS; ++j) {
+            const int idx = tid + j * kThreads;
+            const int row = idx >> 3, ch = idx & 7;
+            const int t = t0 - a.pad + row, ci = c * KC + ch * V;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (t >= 0 && t < t_in_hi && ci < a.c_in) {
+              v = *reinterpret_cast<const u32x4*>(X + (size_t)t * a.ldx + ci);
+              if (a.in_slope != 1.0f) v = lrelu_vec<T>(v, a.in_slope);
+            }
+            xr[c * XS + j] = v;
+          }
+#pragma unroll
+          for (int j = 0; j < WS; ++j) {
+            const int idx = tid + j * kThreads;
+            const int ch = idx & 7, col = idx >> 3;
+            const int co = col_to_co(col), ci = c * KC + ch * V;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (co >= 0 && ci < a.c_in) v = *reinterpret_cast<const u32x4*>(W + (size_t)co * a.ldw + ci);
+            wr[c * WS + j] = v;
+          }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        if (c < n_chunks) {
+          if (c > 0) __syncthreads();                          // every wave is done reading the previous chunk's LDS
+#pragma unroll
+          for (int j = 0; j < XS; ++j) {
+            const int idx = tid + j * kThreads;
+            *reinterpret_cast<u32x4*>(ldsX + (idx >> 3) * PITCHK + (idx & 7) * 16) = xr[c * XS + j];
+          }
+#pragma unroll
+          for (int j = 0; j < WS; ++j) {
+            const int idx = tid + j * kThreads;
+            *reinterpret_cast<u32x4*>(ldsW + (idx >> 3) * PITCHK + (idx & 7) * 16) = wr[c * WS + j];
+          }
+          __syncthreads();
+          mma_tap(0, 0);
+        }
+      }
+      done = true;
+    }
+  }
+
   // ---- software pipeline: the global loads of stage s+1 are in flight while stage s is multiplied
+  if (!done) {
   load_w(0, 0);
   if (x_in_regs) { load_x(0); store_x(); } else stage_x_direct(0);
   store_w(0);
   __syncthreads();
-  for (int s = 0; s < n_stages; ++s) {
+  }
+  for (int s = 0; s < (done ? 0 : n_stages); ++s) {
     const int tg = (s % n_groups) * args.G;
     const int nxt = s + 1;
     const int nci0 = (nxt / n_groups) * KC, ntg = (nxt % n_groups) * args.G;
@@ -207,29 +290,7 @@ __global__ __launch_bounds__(kThreads) void conv1d_cl_kernel(ConvArgs args) {
       if (new_chunk && x_in_regs) load_x(nci0);
     }
     const int ntap = (a.k - tg < args.G) ? (a.k - tg) : args.G;
-    for (int tl = 0; tl < ntap; ++tl) {
-      const unsigned char* xa = ldsX + ((wm * 32 + r) * a.stride + (tg + tl) * a.dil) * PITCHK + 16 * h;
-      const unsigned char* wb = ldsW + (tl * TN + wn * TNW + r) * PITCHK + 16 * h;
-#pragma unroll
-      for (int m = 0; m < 4 * NC; ++m) {
-        const u32x4 av = *reinterpret_cast<const u32x4*>(xa + 32 * m);
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          const u32x4 bv = *reinterpret_cast<const u32x4*>(wb + n * 32 * PITCHK + 32 * m);
-          if constexpr (sizeof(T) == 2) {
-            union { u32x4 u; bf16x8 v; } ua, ub;
-            ua.u = av; ub.u = bv;
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.v, ub.v, acc[n], 0, 0, 0);
-          } else {
-            union { u32x4 u; float f[4]; } ua, ub;
-            ua.u = av; ub.u = bv;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua.f[j], ub.f[j], acc[n], 0, 0, 0);
-          }
-        }
-      }
-    }
+    for (int tl = 0; tl < ntap; ++tl) mma_tap(tg + tl, tl);
     if (has_next) {
       __syncthreads();                       // every wave is done reading this stage's LDS
       store_w(ntg);
