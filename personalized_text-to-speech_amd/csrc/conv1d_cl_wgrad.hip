@@ -361,6 +361,7 @@ __global__ void reduce_slabs(const float* __restrict__ partial, float* __restric
   if (i >= n + nb) return;
   float* dst = (i < n) ? dw + i : db + (i - n);
   float4 acc = accumulate ? *reinterpret_cast<const float4*>(dst) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
   for (int k = 0; k < S; ++k) {
     const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)k * slab + i);
     acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
@@ -379,6 +380,8 @@ __global__ void reduce_pending_kernel(PendingTable tab) {
   for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < total; i += (size_t)gridDim.x * blockDim.x * 4) {
     float* dst = (i < p.n) ? p.dw + i : p.dbias + (i - p.n);
     float4 acc = p.accumulate ? *reinterpret_cast<const float4*>(dst) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // (loads of 8 splits in flight at a time; the additions keep the split order, so the bits do not change)
+#pragma unroll 8
     for (int k = 0; k < p.splits; ++k) {
       const float4 v = *reinterpret_cast<const float4*>(p.partial + (size_t)k * p.slab + i);
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
