@@ -37,6 +37,7 @@ __global__ __launch_bounds__(kThreads) void partial_kernel(const T* __restrict__
   __shared__ float red[4];
   const size_t base = (size_t)blockIdx.y * seg_len;
   float acc = 0.f;
+#pragma unroll 4
   for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < seg_len; i += (size_t)gridDim.x * kThreads) {
     const float x = ld<T>(a, base + i);
     acc += ABSDIFF ? fabsf(x - ld<T>(b, base + i)) : x;
@@ -97,8 +98,10 @@ __global__ __launch_bounds__(kThreads) void colsum_kernel(const T* __restrict__ 
   const int per = (rows + S - 1) / S, r0 = s * per, r1 = (r0 + per < rows) ? r0 + per : rows;
   const T* base = x + (size_t)seg * rows * C;
   float acc = 0.f;
-  if (col < C)
+  if (col < C) {
+#pragma unroll 8
     for (int r = r0 + rl; r < r1; r += 4) acc += ld<T>(base, (size_t)r * C + col);
+  }
   red[rl][threadIdx.x & 63] = acc;
   __syncthreads();
   if (rl == 0 && col < C) dst[((size_t)seg * S + s) * C + col] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];

@@ -193,8 +193,10 @@ __global__ __launch_bounds__(1024) void reduce_partials2(const float* __restrict
   const float* src = part + (isB ? nA : 0);
   float* out = isB ? outB : outA;
   float s = 0.f;
-  if (j < n)
+  if (j < n) {
+#pragma unroll 4
     for (int w = slice; w < W; w += 16) s += src[(size_t)w * stride + j];
+  }
   sm[slice][col] = s;
   __syncthreads();
   if (slice == 0 && j < n) {
