@@ -109,15 +109,29 @@ __global__ __launch_bounds__(256) void ln_act_bwd(const T* __restrict__ x, const
     dg[i] = 0.f; db[i] = 0.f;
   }
   const int r0 = blockIdx.x * rows_per_wg;
-  for (int r = r0 + wave; r < r0 + rows_per_wg && r < rows; r += 4) {
-    float v[NCMAX], a[NCMAX], sum = 0.f;
+  const int r_end = (r0 + rows_per_wg < rows) ? r0 + rows_per_wg : rows;
+  // software pipeline over this wave's rows: the loads of row r + 4 are in flight while row r is reduced (the row chain is
+  // otherwise one exposed load latency per row)
+  float vn[NCMAX], an[NCMAX];
+  auto load_row = [&](int rr) {
 #pragma unroll
     for (int i = 0; i < NCMAX; ++i) {
       const int c = lane + 64 * i;
-      v[i] = (i < nc && c < C) ? to_f(x[(size_t)r * C + c]) : 0.f;
-      a[i] = (i < nc && c < C) ? to_f(dy[(size_t)r * C + c]) : 0.f;
+      const bool ok = i < nc && c < C && rr < r_end;
+      vn[i] = ok ? to_f(x[(size_t)rr * C + c]) : 0.f;
+      an[i] = ok ? to_f(dy[(size_t)rr * C + c]) : 0.f;
+    }
+  };
+  load_row(r0 + wave);
+  for (int r = r0 + wave; r < r_end; r += 4) {
+    float v[NCMAX], a[NCMAX], sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCMAX; ++i) {
+      v[i] = vn[i];
+      a[i] = an[i];
       sum += v[i];
     }
+    load_row(r + 4);
     const float mean = wave_sum(sum) / C;
     float sq = 0.f;
 #pragma unroll
