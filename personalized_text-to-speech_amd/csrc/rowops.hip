@@ -245,39 +245,45 @@ __global__ void dwconv_fwd(const T* __restrict__ x, const float* __restrict__ w,
   }
 }
 
-template <typename T>
+template <typename T, int KC>          // KC = compile-time tap count (3 for the VITS duration predictor), 0 = run-time k
 __global__ void dwconv_bwd(const T* __restrict__ x, const float* __restrict__ w, const int* __restrict__ lengths,
                            const T* __restrict__ dy, T* __restrict__ dx, float* __restrict__ part, int B, int Tn, int C, int k,
                            int dil, int rows_per_wg) {
   const int c = threadIdx.x;
   if (c >= C) return;
+  if (KC > 0) k = KC;
   float wk[8], dw[8];
-  for (int j = 0; j < k; ++j) { wk[j] = w[c * k + j]; dw[j] = 0.f; }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { wk[j] = j < k ? w[c * k + j] : 0.f; dw[j] = 0.f; }
   float db = 0.f;
   const int half = (k - 1) / 2;
   const int r0 = blockIdx.x * rows_per_wg;
+#pragma unroll 2
   for (int r = r0; r < r0 + rows_per_wg && r < B * Tn; ++r) {
     const int b = r / Tn, t = r % Tn;
     const int len = lengths ? lengths[b] : Tn;
     // dx[t] = mask[t] * sum_j w[j] * dy[t - (j-half)*dil]
     float acc = 0.f;
     if (t < len) {
-      for (int j = 0; j < k; ++j) {
+#pragma unroll
+      for (int j = 0; j < (KC > 0 ? KC : 8); ++j) {
         const int to = t - (j - half) * dil;
-        if (to >= 0 && to < Tn) acc += wk[j] * to_f(dy[((size_t)b * Tn + to) * C + c]);
+        if (j < k && to >= 0 && to < Tn) acc += wk[j] * to_f(dy[((size_t)b * Tn + to) * C + c]);
       }
     }
     dx[(size_t)r * C + c] = from_f<T>(acc);
     // dw[j] += dy[t] * xm[t + (j-half)*dil]
     const float g = to_f(dy[(size_t)r * C + c]);
     db += g;
-    for (int j = 0; j < k; ++j) {
+#pragma unroll
+    for (int j = 0; j < (KC > 0 ? KC : 8); ++j) {
       const int ti = t + (j - half) * dil;
-      if (ti >= 0 && ti < Tn && ti < len) dw[j] += g * to_f(x[((size_t)b * Tn + ti) * C + c]);
+      if (j < k && ti >= 0 && ti < Tn && ti < len) dw[j] += g * to_f(x[((size_t)b * Tn + ti) * C + c]);
     }
   }
   float* P = part + (size_t)blockIdx.x * (k + 1) * C;
-  for (int j = 0; j < k; ++j) P[c * k + j] = dw[j];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) if (j < k) P[c * k + j] = dw[j];
   P[k * C + c] = db;
 }
 
@@ -362,9 +368,11 @@ extern "C" int vits_dwconv_cl_bwd(int dtype, const void* x, const float* w, cons
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* part = static_cast<float*>(workspace);
   if (dtype == VITS_DT_BF16)
-    hipLaunchKernelGGL(dwconv_bwd<__bf16>, dim3(wgs), dim3(threads), 0, s, (const __bf16*)x, w, lengths, (const __bf16*)dy, (__bf16*)dx, part, b, t, c, k, dil, rpw);
+    if (k == 3) hipLaunchKernelGGL((dwconv_bwd<__bf16, 3>), dim3(wgs), dim3(threads), 0, s, (const __bf16*)x, w, lengths, (const __bf16*)dy, (__bf16*)dx, part, b, t, c, k, dil, rpw);
+    else hipLaunchKernelGGL((dwconv_bwd<__bf16, 0>), dim3(wgs), dim3(threads), 0, s, (const __bf16*)x, w, lengths, (const __bf16*)dy, (__bf16*)dx, part, b, t, c, k, dil, rpw);
   else if (dtype == VITS_DT_F32)
-    hipLaunchKernelGGL(dwconv_bwd<float>, dim3(wgs), dim3(threads), 0, s, (const float*)x, w, lengths, (const float*)dy, (float*)dx, part, b, t, c, k, dil, rpw);
+    if (k == 3) hipLaunchKernelGGL((dwconv_bwd<float, 3>), dim3(wgs), dim3(threads), 0, s, (const float*)x, w, lengths, (const float*)dy, (float*)dx, part, b, t, c, k, dil, rpw);
+    else hipLaunchKernelGGL((dwconv_bwd<float, 0>), dim3(wgs), dim3(threads), 0, s, (const float*)x, w, lengths, (const float*)dy, (float*)dx, part, b, t, c, k, dil, rpw);
   else return VITS_E_UNSUPPORTED;
   // partial rows are [(k+1)*c]: first k*c = dw[c][k], then c = dbias
   hipLaunchKernelGGL(reduce_partials2, dim3((k * c + 63) / 64 + (c + 63) / 64), dim3(1024), 0, s, part, dw, k * c, dbias, c, wgs, (k + 1) * c, accumulate);
