@@ -126,6 +126,70 @@ int colsum_splits(int n_seg, int rows, int C) {
   return S < 1 ? 1 : S;
 }
 
+// ---- bf16, 8 elements (16 bytes) per thread per step: the element-wise passes over the discriminators' feature maps are
+// instruction-bound with 2-byte loads
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+union Bf8 { u32x4 u; __bf16 e[8]; };
+
+__global__ __launch_bounds__(kThreads) void partial_absdiff_bf16x8(const u32x4* __restrict__ a, const u32x4* __restrict__ b, size_t nvec,
+                                                                  float* __restrict__ partial) {
+  __shared__ float red[4];
+  float acc = 0.f;
+#pragma unroll 2
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += (size_t)gridDim.x * kThreads) {
+    Bf8 x, y;
+    x.u = a[i]; y.u = b[i];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += fabsf((float)x.e[j] - (float)y.e[j]);
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
+__global__ __launch_bounds__(kThreads) void absdiff_bwd_bf16x8(const u32x4* __restrict__ a, const u32x4* __restrict__ b, size_t nvec,
+                                                              const float* __restrict__ g, float scale, u32x4* __restrict__ da,
+                                                              u32x4* __restrict__ db) {
+  const float gs = g[0] * scale;
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += (size_t)gridDim.x * kThreads) {
+    Bf8 x, y, o;
+    x.u = a[i]; y.u = b[i];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float d = (float)x.e[j] - (float)y.e[j];
+      o.e[j] = (__bf16)(d > 0.f ? -gs : (d < 0.f ? gs : 0.f));
+    }
+    db[i] = o.u;
+    if (da) da[i] = u32x4{0u, 0u, 0u, 0u};
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void lrelu_mask_bwd_bf16x8(const u32x4* __restrict__ dy, const u32x4* __restrict__ y, float slope,
+                                                                 const int* __restrict__ lengths, int t, int cvec, size_t nvec,
+                                                                 u32x4* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += (size_t)gridDim.x * kThreads) {
+    Bf8 v, o;
+    v.u = dy[i];
+    bool dead = false;
+    if (lengths) {                                       // all 8 elements of a vector share their row (c % 8 == 0)
+      const size_t row = i / cvec;
+      const int b = (int)(row / t), tt = (int)(row - (size_t)b * t);
+      dead = tt >= lengths[b];
+    }
+    if (y) {
+      Bf8 g;
+      g.u = y[i];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o.e[j] = dead ? (__bf16)0.f : ((float)g.e[j] > 0.f ? v.e[j] : (__bf16)((float)v.e[j] * slope));
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o.e[j] = dead ? (__bf16)0.f : v.e[j];
+    }
+    out[i] = o.u;
+  }
+}
+
+__host__ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 int pick_splits(size_t seg_len, int n_seg) {
   long s = (long)((seg_len + (size_t)kThreads * 8 - 1) / ((size_t)kThreads * 8));     // >= 8 elements per thread
   const long fill = (1024 + n_seg - 1) / n_seg;                                      // ~4 workgroups per CU in total
@@ -146,7 +210,10 @@ extern "C" int vits_absdiff_sum(int dtype, const void* a, const void* b, size_t 
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int splits = pick_splits(n, 1);
   float* part = static_cast<float*>(workspace);
-  if (dtype == VITS_DT_BF16)
+  if (dtype == VITS_DT_BF16 && n % 8 == 0 && aligned16(a) && aligned16(b))
+    hipLaunchKernelGGL(partial_absdiff_bf16x8, dim3(splits, 1), dim3(kThreads), 0, s, static_cast<const u32x4*>(a),
+                       static_cast<const u32x4*>(b), n / 8, part);
+  else if (dtype == VITS_DT_BF16)
     hipLaunchKernelGGL((partial_kernel<__bf16, true>), dim3(splits, 1), dim3(kThreads), 0, s, static_cast<const __bf16*>(a),
                        static_cast<const __bf16*>(b), n, part);
   else if (dtype == VITS_DT_F32)
@@ -164,7 +231,11 @@ extern "C" int vits_absdiff_bwd(int dtype, const void* a, const void* b, size_t 
   hipStream_t s = static_cast<hipStream_t>(stream);
   size_t blocks = (n + (size_t)kThreads * 8 - 1) / ((size_t)kThreads * 8);
   if (blocks > 2048) blocks = 2048;
-  if (dtype == VITS_DT_BF16)
+  if (dtype == VITS_DT_BF16 && n % 8 == 0 && aligned16(a) && aligned16(b) && aligned16(db) && (!da || aligned16(da)))
+    hipLaunchKernelGGL(absdiff_bwd_bf16x8, dim3((unsigned)((n / 8 + kThreads - 1) / kThreads > 2048 ? 2048 : (n / 8 + kThreads - 1) / kThreads)),
+                       dim3(kThreads), 0, s, static_cast<const u32x4*>(a), static_cast<const u32x4*>(b), n / 8, g, scale,
+                       static_cast<u32x4*>(da), static_cast<u32x4*>(db));
+  else if (dtype == VITS_DT_BF16)
     hipLaunchKernelGGL(absdiff_bwd_kernel<__bf16>, dim3((unsigned)blocks), dim3(kThreads), 0, s, static_cast<const __bf16*>(a),
                        static_cast<const __bf16*>(b), n, g, scale, static_cast<__bf16*>(da), static_cast<__bf16*>(db));
   else if (dtype == VITS_DT_F32)
@@ -194,7 +265,11 @@ extern "C" int vits_lrelu_mask_bwd(int dtype, const void* dy, const void* y, flo
   size_t blocks = (n + (size_t)kThreads * 4 - 1) / ((size_t)kThreads * 4);
   if (blocks > 4096) blocks = 4096;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (dtype == VITS_DT_BF16)
+  if (dtype == VITS_DT_BF16 && c % 8 == 0 && aligned16(dy) && aligned16(out) && (!y || aligned16(y)))
+    hipLaunchKernelGGL(lrelu_mask_bwd_bf16x8, dim3((unsigned)((n / 8 + kThreads - 1) / kThreads > 4096 ? 4096 : (n / 8 + kThreads - 1) / kThreads)),
+                       dim3(kThreads), 0, s, static_cast<const u32x4*>(dy), static_cast<const u32x4*>(y), slope, lengths, t, c / 8, n / 8,
+                       static_cast<u32x4*>(out));
+  else if (dtype == VITS_DT_BF16)
     hipLaunchKernelGGL(lrelu_mask_bwd_kernel<__bf16>, dim3((unsigned)blocks), dim3(kThreads), 0, s, static_cast<const __bf16*>(dy),
                        static_cast<const __bf16*>(y), slope, lengths, t, c, n, static_cast<__bf16*>(out));
   else if (dtype == VITS_DT_F32)
