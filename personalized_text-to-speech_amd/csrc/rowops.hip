@@ -58,32 +58,32 @@ __global__ __launch_bounds__(256) void ln_act_fwd(const T* __restrict__ x, const
   float g[NCMAX], bt[NCMAX];
 #pragma unroll
   for (int i = 0; i < NCMAX; ++i) {
-    const int c = lane + 64 * i;
-    g[i] = (i < nc && c < C) ? gamma[c] : 0.f;
-    bt[i] = (i < nc && c < C) ? beta[c] : 0.f;
+    const int c = (NCMAX == 4) ? lane * 4 + i : lane + 64 * i;   // <= 256 channels: 4 adjacent channels per lane (one 8-byte access)
+    g[i] = ((NCMAX == 4 || i < nc) && c < C) ? gamma[c] : 0.f;
+    bt[i] = ((NCMAX == 4 || i < nc) && c < C) ? beta[c] : 0.f;
   }
   const int r0 = blockIdx.x * rows_per_wg;
   for (int r = r0 + wave; r < r0 + rows_per_wg && r < rows; r += 4) {
     float v[NCMAX], sum = 0.f;
 #pragma unroll
     for (int i = 0; i < NCMAX; ++i) {
-      const int c = lane + 64 * i;
-      v[i] = (i < nc && c < C) ? to_f(x[(size_t)r * C + c]) : 0.f;
+      const int c = (NCMAX == 4) ? lane * 4 + i : lane + 64 * i;   // <= 256 channels: 4 adjacent channels per lane (one 8-byte access)
+      v[i] = ((NCMAX == 4 || i < nc) && c < C) ? to_f(x[(size_t)r * C + c]) : 0.f;
       sum += v[i];
     }
     const float mean = wave_sum(sum) / C;
     float sq = 0.f;
 #pragma unroll
     for (int i = 0; i < NCMAX; ++i) {
-      const int c = lane + 64 * i;
-      v[i] = (i < nc && c < C) ? v[i] - mean : 0.f;
+      const int c = (NCMAX == 4) ? lane * 4 + i : lane + 64 * i;   // <= 256 channels: 4 adjacent channels per lane (one 8-byte access)
+      v[i] = ((NCMAX == 4 || i < nc) && c < C) ? v[i] - mean : 0.f;
       sq += v[i] * v[i];
     }
     const float rstd = rsqrtf(wave_sum(sq) / C + eps);
 #pragma unroll
     for (int i = 0; i < NCMAX; ++i) {
-      const int c = lane + 64 * i;
-      if (i < nc && c < C) {
+      const int c = (NCMAX == 4) ? lane * 4 + i : lane + 64 * i;   // <= 256 channels: 4 adjacent channels per lane (one 8-byte access)
+      if ((NCMAX == 4 || i < nc) && c < C) {
         float u = v[i] * rstd * g[i] + bt[i];
         if (act == 1) u = gelu_f(u);
         if (res) u += to_f(res[(size_t)r * C + c]);
@@ -103,9 +103,9 @@ __global__ __launch_bounds__(256) void ln_act_bwd(const T* __restrict__ x, const
   float g[NCMAX], bt[NCMAX], dg[NCMAX], db[NCMAX];
 #pragma unroll
   for (int i = 0; i < NCMAX; ++i) {
-    const int c = lane + 64 * i;
-    g[i] = (i < nc && c < C) ? gamma[c] : 0.f;
-    bt[i] = (i < nc && c < C) ? beta[c] : 0.f;
+    const int c = (NCMAX == 4) ? lane * 4 + i : lane + 64 * i;   // <= 256 channels: 4 adjacent channels per lane (one 8-byte access)
+    g[i] = ((NCMAX == 4 || i < nc) && c < C) ? gamma[c] : 0.f;
+    bt[i] = ((NCMAX == 4 || i < nc) && c < C) ? beta[c] : 0.f;
     dg[i] = 0.f; db[i] = 0.f;
   }
   const int r0 = blockIdx.x * rows_per_wg;
@@ -116,8 +116,8 @@ __global__ __launch_bounds__(256) void ln_act_bwd(const T* __restrict__ x, const
   auto load_row = [&](int rr) {
 #pragma unroll
     for (int i = 0; i < NCMAX; ++i) {
-      const int c = lane + 64 * i;
-      const bool ok = i < nc && c < C && rr < r_end;
+      const int c = (NCMAX == 4) ? lane * 4 + i : lane + 64 * i;   // <= 256 channels: 4 adjacent channels per lane (one 8-byte access)
+      const bool ok = (NCMAX == 4 || i < nc) && c < C && rr < r_end;
       vn[i] = ok ? to_f(x[(size_t)rr * C + c]) : 0.f;
       an[i] = ok ? to_f(dy[(size_t)rr * C + c]) : 0.f;
     }
@@ -136,8 +136,8 @@ __global__ __launch_bounds__(256) void ln_act_bwd(const T* __restrict__ x, const
     float sq = 0.f;
 #pragma unroll
     for (int i = 0; i < NCMAX; ++i) {
-      const int c = lane + 64 * i;
-      v[i] = (i < nc && c < C) ? v[i] - mean : 0.f;
+      const int c = (NCMAX == 4) ? lane * 4 + i : lane + 64 * i;   // <= 256 channels: 4 adjacent channels per lane (one 8-byte access)
+      v[i] = ((NCMAX == 4 || i < nc) && c < C) ? v[i] - mean : 0.f;
       sq += v[i] * v[i];
     }
     const float rstd = rsqrtf(wave_sum(sq) / C + eps);
@@ -157,15 +157,15 @@ __global__ __launch_bounds__(256) void ln_act_bwd(const T* __restrict__ x, const
     const float m1 = wave_sum(s1) / C, m2 = wave_sum(s2) / C;
 #pragma unroll
     for (int i = 0; i < NCMAX; ++i) {
-      const int c = lane + 64 * i;
-      if (i < nc && c < C) dx[(size_t)r * C + c] = from_f<T>(rstd * (a[i] - m1 - v[i] * m2));
+      const int c = (NCMAX == 4) ? lane * 4 + i : lane + 64 * i;   // <= 256 channels: 4 adjacent channels per lane (one 8-byte access)
+      if ((NCMAX == 4 || i < nc) && c < C) dx[(size_t)r * C + c] = from_f<T>(rstd * (a[i] - m1 - v[i] * m2));
     }
   }
   // combine the 4 waves' per-channel sums in a fixed order, one partial row per workgroup
 #pragma unroll
   for (int i = 0; i < NCMAX; ++i) {
-    const int c = lane + 64 * i;
-    if (i < nc && c < C) { red_s[(wave * 2 + 0) * C + c] = dg[i]; red_s[(wave * 2 + 1) * C + c] = db[i]; }
+    const int c = (NCMAX == 4) ? lane * 4 + i : lane + 64 * i;   // <= 256 channels: 4 adjacent channels per lane (one 8-byte access)
+    if ((NCMAX == 4 || i < nc) && c < C) { red_s[(wave * 2 + 0) * C + c] = dg[i]; red_s[(wave * 2 + 1) * C + c] = db[i]; }
   }
   __syncthreads();
   for (int j = threadIdx.x; j < 2 * C; j += 256) {
