@@ -222,24 +222,28 @@ __global__ __launch_bounds__(1024) void reduce_partials2(const float* __restrict
 }
 
 // ---------------------------------------------------------------- depth-wise conv
-template <typename T>
+template <typename T, int KC>          // KC = compile-time tap count (3 for the VITS duration predictor), 0 = run-time k
 __global__ void dwconv_fwd(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                            const int* __restrict__ lengths, T* __restrict__ y, int B, int Tn, int C, int k, int dil,
                            int rows_per_wg) {
   const int c = threadIdx.x;
   if (c >= C) return;
+  if (KC > 0) k = KC;
   float wk[8];
-  for (int j = 0; j < k; ++j) wk[j] = w[c * k + j];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) wk[j] = j < k ? w[c * k + j] : 0.f;
   const float bs = bias ? bias[c] : 0.f;
   const int half = (k - 1) / 2;
   const int r0 = blockIdx.x * rows_per_wg;
+#pragma unroll 2
   for (int r = r0; r < r0 + rows_per_wg && r < B * Tn; ++r) {
     const int b = r / Tn, t = r % Tn;
     const int len = lengths ? lengths[b] : Tn;
     float acc = bs;
-    for (int j = 0; j < k; ++j) {
+#pragma unroll
+    for (int j = 0; j < (KC > 0 ? KC : 8); ++j) {
       const int ti = t + (j - half) * dil;
-      if (ti >= 0 && ti < Tn && ti < len) acc += wk[j] * to_f(x[((size_t)b * Tn + ti) * C + c]);
+      if (j < k && ti >= 0 && ti < Tn && ti < len) acc += wk[j] * to_f(x[((size_t)b * Tn + ti) * C + c]);
     }
     y[(size_t)r * C + c] = from_f<T>(acc);
   }
@@ -350,9 +354,11 @@ extern "C" int vits_dwconv_cl(int dtype, const void* x, const float* w, const fl
   const int rows = b * t, threads = ((c + 63) / 64) * 64, rpw = pick_rows_per_wg(rows), wgs = (rows + rpw - 1) / rpw;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == VITS_DT_BF16)
-    hipLaunchKernelGGL(dwconv_fwd<__bf16>, dim3(wgs), dim3(threads), 0, s, (const __bf16*)x, w, bias, lengths, (__bf16*)y, b, t, c, k, dil, rpw);
+    if (k == 3) hipLaunchKernelGGL((dwconv_fwd<__bf16, 3>), dim3(wgs), dim3(threads), 0, s, (const __bf16*)x, w, bias, lengths, (__bf16*)y, b, t, c, k, dil, rpw);
+    else hipLaunchKernelGGL((dwconv_fwd<__bf16, 0>), dim3(wgs), dim3(threads), 0, s, (const __bf16*)x, w, bias, lengths, (__bf16*)y, b, t, c, k, dil, rpw);
   else if (dtype == VITS_DT_F32)
-    hipLaunchKernelGGL(dwconv_fwd<float>, dim3(wgs), dim3(threads), 0, s, (const float*)x, w, bias, lengths, (float*)y, b, t, c, k, dil, rpw);
+    if (k == 3) hipLaunchKernelGGL((dwconv_fwd<float, 3>), dim3(wgs), dim3(threads), 0, s, (const float*)x, w, bias, lengths, (float*)y, b, t, c, k, dil, rpw);
+    else hipLaunchKernelGGL((dwconv_fwd<float, 0>), dim3(wgs), dim3(threads), 0, s, (const float*)x, w, bias, lengths, (float*)y, b, t, c, k, dil, rpw);
   else return VITS_E_UNSUPPORTED;
   return vits::check_launch("vits_dwconv_cl");
 }
