@@ -50,6 +50,32 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// 4 adjacent channels in one access (8 bytes of bf16 / 16 bytes of float); p must be aligned to that size
+template <typename T>
+__device__ __forceinline__ void load4(const T* p, bool ok, float (&o)[4]) {
+  if (!ok) { o[0] = o[1] = o[2] = o[3] = 0.f; return; }
+  if constexpr (sizeof(T) == 2) {
+    union { uint2 u; T e[4]; } v;
+    v.u = *reinterpret_cast<const uint2*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = to_f(v.e[i]);
+  } else {
+    const float4 f = *reinterpret_cast<const float4*>(p);
+    o[0] = f.x; o[1] = f.y; o[2] = f.z; o[3] = f.w;
+  }
+}
+template <typename T>
+__device__ __forceinline__ void store4(T* p, const float (&o)[4]) {
+  if constexpr (sizeof(T) == 2) {
+    union { uint2 u; T e[4]; } v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v.e[i] = from_f<T>(o[i]);
+    *reinterpret_cast<uint2*>(p) = v.u;
+  } else {
+    *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 template <typename T, int NCMAX>
 __global__ __launch_bounds__(256) void ln_act_fwd(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                            const T* __restrict__ res, T* __restrict__ y, int rows, int C, float eps, int act, int rows_per_wg) {
@@ -65,11 +91,18 @@ __global__ __launch_bounds__(256) void ln_act_fwd(const T* __restrict__ x, const
   const int r0 = blockIdx.x * rows_per_wg;
   for (int r = r0 + wave; r < r0 + rows_per_wg && r < rows; r += 4) {
     float v[NCMAX], sum = 0.f;
+    if constexpr (NCMAX == 4) {
+      float q[4];
+      load4<T>(x + (size_t)r * C + lane * 4, lane * 4 < C, q);
 #pragma unroll
-    for (int i = 0; i < NCMAX; ++i) {
-      const int c = (NCMAX == 4) ? lane * 4 + i : lane + 64 * i;   // <= 256 channels: 4 adjacent channels per lane (one 8-byte access)
-      v[i] = ((NCMAX == 4 || i < nc) && c < C) ? to_f(x[(size_t)r * C + c]) : 0.f;
-      sum += v[i];
+      for (int i = 0; i < 4; ++i) { v[i] = q[i]; sum += q[i]; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NCMAX; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = (i < nc && c < C) ? to_f(x[(size_t)r * C + c]) : 0.f;
+        sum += v[i];
+      }
     }
     const float mean = wave_sum(sum) / C;
     float sq = 0.f;
@@ -80,14 +113,28 @@ __global__ __launch_bounds__(256) void ln_act_fwd(const T* __restrict__ x, const
       sq += v[i] * v[i];
     }
     const float rstd = rsqrtf(wave_sum(sq) / C + eps);
+    if constexpr (NCMAX == 4) {
+      if (lane * 4 < C) {
+        float rq[4] = {0.f, 0.f, 0.f, 0.f}, u[4];
+        if (res) load4<T>(res + (size_t)r * C + lane * 4, true, rq);
 #pragma unroll
-    for (int i = 0; i < NCMAX; ++i) {
-      const int c = (NCMAX == 4) ? lane * 4 + i : lane + 64 * i;   // <= 256 channels: 4 adjacent channels per lane (one 8-byte access)
-      if ((NCMAX == 4 || i < nc) && c < C) {
-        float u = v[i] * rstd * g[i] + bt[i];
-        if (act == 1) u = gelu_f(u);
-        if (res) u += to_f(res[(size_t)r * C + c]);
-        y[(size_t)r * C + c] = from_f<T>(u);
+        for (int i = 0; i < 4; ++i) {
+          float w_ = v[i] * rstd * g[i] + bt[i];
+          if (act == 1) w_ = gelu_f(w_);
+          u[i] = w_ + rq[i];
+        }
+        store4<T>(y + (size_t)r * C + lane * 4, u);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NCMAX; ++i) {
+        const int c = lane + 64 * i;
+        if (i < nc && c < C) {
+          float u = v[i] * rstd * g[i] + bt[i];
+          if (act == 1) u = gelu_f(u);
+          if (res) u += to_f(res[(size_t)r * C + c]);
+          y[(size_t)r * C + c] = from_f<T>(u);
+        }
       }
     }
   }
@@ -114,12 +161,21 @@ __global__ __launch_bounds__(256) void ln_act_bwd(const T* __restrict__ x, const
   // otherwise one exposed load latency per row)
   float vn[NCMAX], an[NCMAX];
   auto load_row = [&](int rr) {
+    if constexpr (NCMAX == 4) {
+      const bool ok = lane * 4 < C && rr < r_end;
+      float q[4], p[4];
+      load4<T>(x + (size_t)rr * C + lane * 4, ok, q);
+      load4<T>(dy + (size_t)rr * C + lane * 4, ok, p);
 #pragma unroll
-    for (int i = 0; i < NCMAX; ++i) {
-      const int c = (NCMAX == 4) ? lane * 4 + i : lane + 64 * i;   // <= 256 channels: 4 adjacent channels per lane (one 8-byte access)
-      const bool ok = (NCMAX == 4 || i < nc) && c < C && rr < r_end;
-      vn[i] = ok ? to_f(x[(size_t)rr * C + c]) : 0.f;
-      an[i] = ok ? to_f(dy[(size_t)rr * C + c]) : 0.f;
+      for (int i = 0; i < 4; ++i) { vn[i] = q[i]; an[i] = p[i]; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NCMAX; ++i) {
+        const int c = lane + 64 * i;
+        const bool ok = i < nc && c < C && rr < r_end;
+        vn[i] = ok ? to_f(x[(size_t)rr * C + c]) : 0.f;
+        an[i] = ok ? to_f(dy[(size_t)rr * C + c]) : 0.f;
+      }
     }
   };
   load_row(r0 + wave);
@@ -155,10 +211,19 @@ __global__ __launch_bounds__(256) void ln_act_bwd(const T* __restrict__ x, const
       s2 += a[i] * xh;
     }
     const float m1 = wave_sum(s1) / C, m2 = wave_sum(s2) / C;
+    if constexpr (NCMAX == 4) {
+      if (lane * 4 < C) {
+        float u[4];
 #pragma unroll
-    for (int i = 0; i < NCMAX; ++i) {
-      const int c = (NCMAX == 4) ? lane * 4 + i : lane + 64 * i;   // <= 256 channels: 4 adjacent channels per lane (one 8-byte access)
-      if ((NCMAX == 4 || i < nc) && c < C) dx[(size_t)r * C + c] = from_f<T>(rstd * (a[i] - m1 - v[i] * m2));
+        for (int i = 0; i < 4; ++i) u[i] = rstd * (a[i] - m1 - v[i] * m2);
+        store4<T>(dx + (size_t)r * C + lane * 4, u);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NCMAX; ++i) {
+        const int c = lane + 64 * i;
+        if (i < nc && c < C) dx[(size_t)r * C + c] = from_f<T>(rstd * (a[i] - m1 - v[i] * m2));
+      }
     }
   }
   // combine the 4 waves' per-channel sums in a fixed order, one partial row per workgroup
@@ -316,10 +381,10 @@ extern "C" int vits_ln_act_cl(int dtype, const void* x, const float* gamma, cons
   const int threads = 256, rpw = pick_rows_per_wg(rows, 1024), wgs = (rows + rpw - 1) / rpw;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == VITS_DT_BF16)
-    if (c <= 256) hipLaunchKernelGGL((ln_act_fwd<__bf16, 4>), dim3(wgs), dim3(threads), 0, s, (const __bf16*)x, gamma, beta, (const __bf16*)res, (__bf16*)y, rows, c, eps, act, rpw);
+    if (c <= 256 && c % 4 == 0) hipLaunchKernelGGL((ln_act_fwd<__bf16, 4>), dim3(wgs), dim3(threads), 0, s, (const __bf16*)x, gamma, beta, (const __bf16*)res, (__bf16*)y, rows, c, eps, act, rpw);
     else hipLaunchKernelGGL((ln_act_fwd<__bf16, kNcMax>), dim3(wgs), dim3(threads), 0, s, (const __bf16*)x, gamma, beta, (const __bf16*)res, (__bf16*)y, rows, c, eps, act, rpw);
   else if (dtype == VITS_DT_F32)
-    if (c <= 256) hipLaunchKernelGGL((ln_act_fwd<float, 4>), dim3(wgs), dim3(threads), 0, s, (const float*)x, gamma, beta, (const float*)res, (float*)y, rows, c, eps, act, rpw);
+    if (c <= 256 && c % 4 == 0) hipLaunchKernelGGL((ln_act_fwd<float, 4>), dim3(wgs), dim3(threads), 0, s, (const float*)x, gamma, beta, (const float*)res, (float*)y, rows, c, eps, act, rpw);
     else hipLaunchKernelGGL((ln_act_fwd<float, kNcMax>), dim3(wgs), dim3(threads), 0, s, (const float*)x, gamma, beta, (const float*)res, (float*)y, rows, c, eps, act, rpw);
   else return VITS_E_UNSUPPORTED;
   return vits::check_launch("vits_ln_act_cl");
@@ -336,10 +401,10 @@ extern "C" int vits_ln_act_cl_bwd(int dtype, const void* x, const float* gamma, 
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* part = static_cast<float*>(workspace);
   if (dtype == VITS_DT_BF16)
-    if (c <= 256) hipLaunchKernelGGL((ln_act_bwd<__bf16, 4>), dim3(wgs), dim3(threads), lds, s, (const __bf16*)x, gamma, beta, (const __bf16*)dy, (__bf16*)dx, part, rows, c, eps, act, rpw);
+    if (c <= 256 && c % 4 == 0) hipLaunchKernelGGL((ln_act_bwd<__bf16, 4>), dim3(wgs), dim3(threads), lds, s, (const __bf16*)x, gamma, beta, (const __bf16*)dy, (__bf16*)dx, part, rows, c, eps, act, rpw);
     else hipLaunchKernelGGL((ln_act_bwd<__bf16, kNcMax>), dim3(wgs), dim3(threads), lds, s, (const __bf16*)x, gamma, beta, (const __bf16*)dy, (__bf16*)dx, part, rows, c, eps, act, rpw);
   else if (dtype == VITS_DT_F32)
-    if (c <= 256) hipLaunchKernelGGL((ln_act_bwd<float, 4>), dim3(wgs), dim3(threads), lds, s, (const float*)x, gamma, beta, (const float*)dy, (float*)dx, part, rows, c, eps, act, rpw);
+    if (c <= 256 && c % 4 == 0) hipLaunchKernelGGL((ln_act_bwd<float, 4>), dim3(wgs), dim3(threads), lds, s, (const float*)x, gamma, beta, (const float*)dy, (float*)dx, part, rows, c, eps, act, rpw);
     else hipLaunchKernelGGL((ln_act_bwd<float, kNcMax>), dim3(wgs), dim3(threads), lds, s, (const float*)x, gamma, beta, (const float*)dy, (float*)dx, part, rows, c, eps, act, rpw);
   else return VITS_E_UNSUPPORTED;
   // partials are [wg][2][c]: dgamma then dbeta
