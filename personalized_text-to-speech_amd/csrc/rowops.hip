@@ -356,6 +356,134 @@ __global__ void dwconv_bwd(const T* __restrict__ x, const float* __restrict__ w,
   P[k * C + c] = db;
 }
 
+// ---- 8-channel vector form of the depth-wise convolution (k = 3, C % 8 == 0): a thread owns 8 adjacent channels (16-byte
+// accesses for bf16) and one of RL = 256 / (C/8) row lanes; the backward sums its per-lane weight / bias partials over the row
+// lanes through LDS in a fixed order before writing the workgroup's partial row.
+template <typename T>
+__device__ __forceinline__ void load8(const T* p, bool ok, float (&o)[8]) {
+  if (!ok) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = 0.f;
+    return;
+  }
+  if constexpr (sizeof(T) == 2) {
+    union { uint4 u; T e[8]; } v;
+    v.u = *reinterpret_cast<const uint4*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = to_f(v.e[i]);
+  } else {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+  }
+}
+template <typename T>
+__device__ __forceinline__ void store8(T* p, const float (&o)[8]) {
+  if constexpr (sizeof(T) == 2) {
+    union { uint4 u; T e[8]; } v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v.e[i] = from_f<T>(o[i]);
+    *reinterpret_cast<uint4*>(p) = v.u;
+  } else {
+    *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(o[4], o[5], o[6], o[7]);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv3_fwd_v8(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                      const int* __restrict__ lengths, T* __restrict__ y, int B, int Tn, int C, int dil,
+                                                      int rows_per_wg) {
+  const int cg = C >> 3, RL = 256 / cg;
+  const int g = threadIdx.x % cg, rl = threadIdx.x / cg;
+  if (rl >= RL) return;
+  const int c0 = g * 8;
+  float wk[8][3], bs[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) wk[i][j] = w[(c0 + i) * 3 + j];
+    bs[i] = bias ? bias[c0 + i] : 0.f;
+  }
+  const int r0 = blockIdx.x * rows_per_wg;
+  const int r_end = (r0 + rows_per_wg < B * Tn) ? r0 + rows_per_wg : B * Tn;
+  for (int r = r0 + rl; r < r_end; r += RL) {
+    const int b = r / Tn, t = r - b * Tn;
+    const int len = lengths ? lengths[b] : Tn;
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = bs[i];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int ti = t + (j - 1) * dil;
+      float v[8];
+      load8<T>(x + ((size_t)b * Tn + ti) * C + c0, ti >= 0 && ti < Tn && ti < len, v);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += wk[i][j] * v[i];
+    }
+    store8<T>(y + (size_t)r * C + c0, acc);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv3_bwd_v8(const T* __restrict__ x, const float* __restrict__ w, const int* __restrict__ lengths,
+                                                      const T* __restrict__ dy, T* __restrict__ dx, float* __restrict__ part, int B, int Tn,
+                                                      int C, int dil, int rows_per_wg) {
+  extern __shared__ float red_v8[];                 // [256 threads][32]: per-thread dw[8][3] + db[8]
+  const int cg = C >> 3, RL = 256 / cg;
+  const int g = threadIdx.x % cg, rl = threadIdx.x / cg;
+  const bool active = rl < RL;
+  const int c0 = g * 8;
+  float wk[8][3], dw[8][3], db[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { wk[i][j] = active ? w[(c0 + i) * 3 + j] : 0.f; dw[i][j] = 0.f; }
+    db[i] = 0.f;
+  }
+  const int r0 = blockIdx.x * rows_per_wg;
+  const int r_end = (r0 + rows_per_wg < B * Tn) ? r0 + rows_per_wg : B * Tn;
+  if (active) {
+    for (int r = r0 + rl; r < r_end; r += RL) {
+      const int b = r / Tn, t = r - b * Tn;
+      const int len = lengths ? lengths[b] : Tn;
+      float acc[8], gq[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+      load8<T>(dy + (size_t)r * C + c0, true, gq);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        // dx[t] = mask[t] * sum_j w[j] * dy[t - (j-1)*dil];   dw[j] += dy[t] * xm[t + (j-1)*dil]
+        const int to = t - (j - 1) * dil, ti = t + (j - 1) * dil;
+        float v[8], xv[8];
+        load8<T>(dy + ((size_t)b * Tn + to) * C + c0, t < len && to >= 0 && to < Tn, v);
+        load8<T>(x + ((size_t)b * Tn + ti) * C + c0, ti >= 0 && ti < Tn && ti < len, xv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { acc[i] += wk[i][j] * v[i]; dw[i][j] += gq[i] * xv[i]; }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) db[i] += gq[i];
+      store8<T>(dx + (size_t)r * C + c0, acc);
+    }
+  }
+  // sum over the row lanes in lane order (fixed => reproducible), then one partial row per workgroup: [c][3] then [c]
+  float* mine = red_v8 + (size_t)threadIdx.x * 32;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) mine[i * 3 + j] = dw[i][j];
+    mine[24 + i] = db[i];
+  }
+  __syncthreads();
+  float* P = part + (size_t)blockIdx.x * 4 * C;
+  for (int idx = threadIdx.x; idx < cg * 32; idx += 256) {
+    const int gg = idx / 32, e = idx - gg * 32;
+    float sum = 0.f;
+    for (int l = 0; l < RL; ++l) sum += red_v8[((size_t)(l * cg + gg)) * 32 + e];
+    if (e < 24) P[(gg * 8 + e / 3) * 3 + (e % 3)] = sum;
+    else P[3 * C + gg * 8 + (e - 24)] = sum;
+  }
+}
+
 // forward kernels: up to 512 workgroups; backward kernels write one partial row per workgroup, so
 // fewer (<= 96) keeps the second-stage sum short
 int pick_rows_per_wg(int rows, int max_wgs = 512) {
@@ -418,6 +546,12 @@ extern "C" int vits_dwconv_cl(int dtype, const void* x, const float* w, const fl
   if (c > 1024 || k > 8 || (k % 2) == 0) return VITS_E_UNSUPPORTED;
   const int rows = b * t, threads = ((c + 63) / 64) * 64, rpw = pick_rows_per_wg(rows), wgs = (rows + rpw - 1) / rpw;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (k == 3 && c % 8 == 0 && c >= 64) {                     // 8-channel vector form
+    if (dtype == VITS_DT_BF16) hipLaunchKernelGGL(dwconv3_fwd_v8<__bf16>, dim3(wgs), dim3(256), 0, s, (const __bf16*)x, w, bias, lengths, (__bf16*)y, b, t, c, dil, rpw);
+    else if (dtype == VITS_DT_F32) hipLaunchKernelGGL(dwconv3_fwd_v8<float>, dim3(wgs), dim3(256), 0, s, (const float*)x, w, bias, lengths, (float*)y, b, t, c, dil, rpw);
+    else return VITS_E_UNSUPPORTED;
+    return vits::check_launch("vits_dwconv_cl");
+  }
   if (dtype == VITS_DT_BF16)
     if (k == 3) hipLaunchKernelGGL((dwconv_fwd<__bf16, 3>), dim3(wgs), dim3(threads), 0, s, (const __bf16*)x, w, bias, lengths, (__bf16*)y, b, t, c, k, dil, rpw);
     else hipLaunchKernelGGL((dwconv_fwd<__bf16, 0>), dim3(wgs), dim3(threads), 0, s, (const __bf16*)x, w, bias, lengths, (__bf16*)y, b, t, c, k, dil, rpw);
@@ -438,6 +572,14 @@ extern "C" int vits_dwconv_cl_bwd(int dtype, const void* x, const float* w, cons
   const int threads = ((c + 63) / 64) * 64, rpw = pick_rows_per_wg(rows, kBwdWgs), wgs = (rows + rpw - 1) / rpw;
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* part = static_cast<float*>(workspace);
+  if (k == 3 && c % 8 == 0 && c >= 64) {                     // 8-channel vector form
+    const size_t lds = 256 * 32 * sizeof(float);
+    if (dtype == VITS_DT_BF16) hipLaunchKernelGGL(dwconv3_bwd_v8<__bf16>, dim3(wgs), dim3(256), lds, s, (const __bf16*)x, w, lengths, (const __bf16*)dy, (__bf16*)dx, part, b, t, c, dil, rpw);
+    else if (dtype == VITS_DT_F32) hipLaunchKernelGGL(dwconv3_bwd_v8<float>, dim3(wgs), dim3(256), lds, s, (const float*)x, w, lengths, (const float*)dy, (float*)dx, part, b, t, c, dil, rpw);
+    else return VITS_E_UNSUPPORTED;
+    hipLaunchKernelGGL(reduce_partials2, dim3((k * c + 63) / 64 + (c + 63) / 64), dim3(1024), 0, s, part, dw, k * c, dbias, c, wgs, (k + 1) * c, accumulate);
+    return vits::check_launch("vits_dwconv_cl_bwd");
+  }
   if (dtype == VITS_DT_BF16)
     if (k == 3) hipLaunchKernelGGL((dwconv_bwd<__bf16, 3>), dim3(wgs), dim3(threads), 0, s, (const __bf16*)x, w, lengths, (const __bf16*)dy, (__bf16*)dx, part, b, t, c, k, dil, rpw);
     else hipLaunchKernelGGL((dwconv_bwd<__bf16, 0>), dim3(wgs), dim3(threads), 0, s, (const __bf16*)x, w, lengths, (const __bf16*)dy, (__bf16*)dx, part, b, t, c, k, dil, rpw);
