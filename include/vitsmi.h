@@ -329,6 +329,44 @@ int vits_colsum(int dtype, const void* x, int n_seg, int rows, int c, float* out
 int vits_lrelu_mask_bwd(int dtype, const void* dy, const void* y, float slope, const int32_t* lengths, int b, int t, int c,
                         void* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Discriminator edge layers as bandwidth kernels (csrc/disc_edge.hip).
+ *
+ * Replaces: the first convolution of every discriminator together with the pad / view it sits behind —
+ *           models.py:318-325 (DiscriminatorP: F.pad(reflect) to a multiple of the period, view [b,1,T/p,p],
+ *           weight-normed Conv2d(1, 32, (5,1), (3,1), padding (2,0)), leaky_relu 0.1) and models.py:353-356
+ *           (DiscriminatorS: Conv1d(1, 16, 15, 1, padding 7), leaky_relu) — and conv_post (models.py:312,330 /
+ *           :349,358: 1024 -> 1 channels, k 3), and the autograd of both.
+ *   x      float32 [n][T]  raw waveforms (real items first, generated items second);
+ *   period p (1 = DiscriminatorS): item j = n_idx*p + w of the folded tensor is column w of the [T/p, p] view;
+ *   h1     [(n,w)][R1][c_out] channels-last, R1 = vits_disc_first_rows(T, p, k, s1, pad), leaky_relu(slope) applied;
+ *   w      the arena operand [k][c_out][8] (input channel 0 live), dw the arena's fp32 gradient of the same shape
+ *          (only [tap][co][0] is written); bias / dbias float32[c_out];
+ *   dy     gradient wrt the PRE-activation of h1 (the caller's data-gradient launch applies lrelu'), same layout as h1;
+ *   vits_disc_first_dgrad: dx float32 [n - n_lo][T] (+)= gradient wrt the waveforms of items n_lo..n-1 (the generated half
+ *          in the generator step), reflect pad folded back.
+ *   conv_post: h [(n,w)][R][c_in], w arena operand [k][8][c_in] (output channel 0 live), y8 / dy8 [(n,w)][R][8]
+ *          (channel 0 live; y8 channels 1..7 are written as 0);
+ *   vits_disc_post_dgrad: dh = (conv^T(dy8) + res) * lrelu'_{slope}(h) for the rows of items j_lo..J-1 (res optional:
+ *          the feature-matching gradient of h); vits_disc_post_wgrad: dw [tap][0][:] and dbias[0] (+)=.
+ *   workspaces: per-block partial sums, reduced in a fixed order by a second launch (bitwise reproducible).
+ * ------------------------------------------------------------------------------------------ */
+int vits_disc_first_rows(int T, int p, int k, int s1, int pad);
+int vits_disc_first_fwd(int dtype, const float* x, const void* w, const float* bias, void* y, int n, int T, int p, int k, int s1,
+                        int pad, int c_out, float slope, void* stream);
+size_t vits_disc_first_wgrad_workspace(int n, int T, int p, int k, int s1, int pad, int c_out);
+int vits_disc_first_wgrad(int dtype, const float* x, const void* dy, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
+                          int n, int T, int p, int k, int s1, int pad, int c_out, int accumulate, void* stream);
+int vits_disc_first_dgrad(int dtype, const void* dy, const void* w, float* dx, int n, int n_lo, int T, int p, int k, int s1, int pad,
+                          int c_out, int accumulate, void* stream);
+int vits_disc_post_fwd(int dtype, const void* h, const void* w, const float* bias, void* y8, int J, int R, int c_in, int k, int pad,
+                       void* stream);
+int vits_disc_post_dgrad(int dtype, const void* dy8, const void* w, const void* res, const void* h, void* dh, int J, int R, int c_in,
+                         int k, int pad, int j_lo, float slope, void* stream);
+size_t vits_disc_post_wgrad_workspace(int J, int R, int c_in, int k);
+int vits_disc_post_wgrad(int dtype, const void* dy8, const void* h, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
+                         int J, int R, int c_in, int k, int pad, int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

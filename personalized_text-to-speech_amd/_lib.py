@@ -10,7 +10,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvitsmi.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 c_int = ctypes.c_int
 c_void_p = ctypes.c_void_p
@@ -49,6 +49,15 @@ SIGNATURES = {
     "vits_conv1d_cl_wgrad_deferred": (c_int, [c_void_p, c_void_p, c_void_p]),
     "vits_wgrad_reduce_pending": (c_int, [c_void_p, c_int, c_void_p]),
     "vits_conv1d_cl": (c_int, [c_void_p, c_void_p]),
+    "vits_disc_first_rows": (c_int, [c_int] * 5),
+    "vits_disc_first_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_float, c_void_p]),
+    "vits_disc_first_wgrad_workspace": (c_size_t, [c_int] * 7),
+    "vits_disc_first_wgrad": (c_int, [c_int] + [c_void_p] * 5 + [c_size_t] + [c_int] * 8 + [c_void_p]),
+    "vits_disc_first_dgrad": (c_int, [c_int] + [c_void_p] * 3 + [c_int] * 9 + [c_void_p]),
+    "vits_disc_post_fwd": (c_int, [c_int] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
+    "vits_disc_post_dgrad": (c_int, [c_int] + [c_void_p] * 5 + [c_int] * 6 + [c_float, c_void_p]),
+    "vits_disc_post_wgrad_workspace": (c_size_t, [c_int] * 4),
+    "vits_disc_post_wgrad": (c_int, [c_int] + [c_void_p] * 5 + [c_size_t] + [c_int] * 6 + [c_void_p]),
 }
 
 class ConvDesc(ctypes.Structure):

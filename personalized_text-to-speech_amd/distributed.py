@@ -20,9 +20,15 @@ def broadcast_parameters(module, src=0):
     """DDP's constructor-time broadcast (rank 0 -> all) of parameters and buffers."""
     if world() == 1:
         return
+    staged = dist.get_backend() != "nccl"            # gloo rehearsal with device tensors: through a host copy
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
-            dist.broadcast(t.data, src)
+            if staged and t.is_cuda:
+                h = t.data.cpu()
+                dist.broadcast(h, src)
+                t.data.copy_(h)
+            else:
+                dist.broadcast(t.data, src)
 
 
 class GradBuckets:
@@ -94,6 +100,8 @@ class GradBuckets:
             p.grad = v
         if dist.get_backend(self.group) == "nccl":
             self._work.append(dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
+        elif flat.is_cuda:
+            self._host_all_reduce(flat)
         else:
             self._work.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat))
 
@@ -119,9 +127,18 @@ class GradBuckets:
         for flat, _, _ in self.buckets:
             if dist.get_backend(self.group) == "nccl":
                 dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
+            elif flat.is_cuda:
+                self._host_all_reduce(flat)
             else:
                 dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
                 flat.div_(self.world)
+
+    def _host_all_reduce(self, flat):
+        """Rehearsal path (gloo with device tensors, e.g. several ranks sharing one GPU in a test): average through a host
+        copy, synchronously.  The production backend is "nccl" (RCCL over xGMI)."""
+        host = flat.detach().cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+        flat.copy_(host.div_(self.world))
 
     def _on_grad(self, p):
         if not self._enabled or self._manual:

@@ -286,36 +286,62 @@ def workspace(nbytes, device):
 class DeferredReductions:
     """Collects the second stages of a group of weight-gradient launches (vits_conv1d_cl_wgrad_deferred) and runs them as ONE
     launch (vits_wgrad_reduce_pending).  Each deferred call gets its own slice of a per-stream slab buffer shared by all
-    collectors (bump allocation; the space is recycled when no collector has anything pending); when the buffer is full the
-    collector flushes early or the call falls back to the immediate form.  Used by the fused layer nodes and by the weight
+    collectors (bump allocation; the space is recycled when no collector has anything pending).  The buffer starts small and
+    grows to what one backward needs (grow-only, re-allocated only while nothing is pending, i.e. during the warm-up steps
+    before a graph capture); when it is full mid-backward the collector flushes early or the call falls back to the immediate
+    form.  A collector belongs to the stream of its first add(): flushing from another stream is an error (the slabs would
+    be reduced without a dependency on the launches that wrote them).  Used by the fused layer nodes and by the weight
     arena, whose weight gradients are only consumed after their backward returns."""
-    CAPACITY = 1 << 30
-    _state = {}                  # (device, stream) -> [buffer, bump offset, pending entries of all collectors]
+    INITIAL = 32 << 20
+    LIMIT = 1 << 30
+    _state = {}                  # (device, stream) -> [buffer, bump offset, pending entries of all collectors, high-water mark, bytes since the last reset]
 
     def __init__(self, device):
-        self.device, self.pending = device, []
+        self.device, self.pending, self.stream = device, [], None
+
+    def _key(self):
+        return (self.device, torch.cuda.current_stream(self.device).cuda_stream)
 
     def _st(self):
-        key = (self.device, torch.cuda.current_stream(self.device).cuda_stream)
+        key = self._key()
+        if self.stream is not None and key[1] != self.stream:
+            raise RuntimeError("DeferredReductions: used from a different stream than the one its pending launches ran on")
         st = DeferredReductions._state.get(key)
         if st is None:
-            st = DeferredReductions._state[key] = [torch.empty(self.CAPACITY, dtype=torch.uint8, device=self.device), 0, 0]
+            # a new stream (e.g. the capture stream after warm-up on a side stream) starts at the largest need seen so far on
+            # this device: inside a capture the buffer cannot be replaced any more
+            seen = max([v[3] for k, v in DeferredReductions._state.items() if k[0] == key[0]], default=0)
+            size = max(self.INITIAL, min(self.LIMIT, (seen * 5 // 4 + 255) & ~255))
+            st = DeferredReductions._state[key] = [torch.empty(size, dtype=torch.uint8, device=self.device), 0, 0, seen, 0]
         return st
 
     def alloc(self, nbytes):
         nbytes = (nbytes + 255) & ~255
         st = self._st()
-        if st[1] + nbytes > self.CAPACITY:
-            self.flush()
-        if st[1] + nbytes > self.CAPACITY:
+        early = False
+        if st[1] + nbytes > st[0].numel():
+            run = st[4]
+            self.flush()                                  # early flush: the buffer is too small for this backward
+            st[4], early = run, True
+        if st[1] + nbytes > st[0].numel() and st[2] == 0 and not torch.cuda.is_current_stream_capturing():
+            want = max(2 * st[0].numel(), st[3] * 5 // 4, nbytes)
+            if want <= self.LIMIT:
+                st[0] = torch.empty(want, dtype=torch.uint8, device=self.device)      # nothing pending: safe to replace
+                st[1] = 0
+        st[4] += nbytes
+        st[3] = max(st[3], st[4])                         # bytes one backward would need without early flushes
+        if st[1] + nbytes > st[0].numel():
             return None                                   # caller falls back to the immediate form
         view = st[0][st[1]:st[1] + nbytes]
         st[1] += nbytes
         return view
 
     def add(self, pend):
+        st = self._st()
+        if self.stream is None:
+            self.stream = self._key()[1]
         self.pending.append(pend)
-        self._st()[2] += 1
+        st[2] += 1
 
     def flush(self):
         if not self.pending:
@@ -326,9 +352,9 @@ class DeferredReductions:
         rc = _lib.lib().vits_wgrad_reduce_pending(ctypes.addressof(arr), len(self.pending), _lib.stream_ptr())
         _lib.check(rc, "vits_wgrad_reduce_pending")
         st[2] -= len(self.pending)
-        self.pending = []
+        self.pending, self.stream = [], None
         if st[2] <= 0:
-            st[1], st[2] = 0, 0
+            st[1], st[2], st[4] = 0, 0, 0
 
 
 _counters = {}

@@ -98,12 +98,19 @@ def spectrogram_torch(y, n_fft, sampling_rate, hop_size, win_size, center=False)
 
 def spec_to_mel_torch(spec, n_fft, num_mels, sampling_rate, fmin, fmax):
     # reference mel_processing.py:73-82: mel basis @ linear-magnitude spec, then log(clamp(., 1e-5))
-    basis = _basis(sampling_rate, n_fft, num_mels, fmin, fmax, spec.dtype, spec.device)
+    return _mel(spec, _basis(sampling_rate, n_fft, num_mels, fmin, fmax, spec.dtype, spec.device))
+
+
+def _mel(spec, basis):
+    """log(clamp(basis @ spec, 1e-5)) in the dtype of `spec` even inside an autocast region: the c_mel = 45 loss is taken on
+    this product, and the reference's mel path is fp32 (mel_processing.py:104 `y.float()`)."""
+    if spec.is_cuda and torch.is_autocast_enabled():
+        with torch.autocast("cuda", enabled=False):
+            return spectral_normalize_torch(torch.matmul(basis, spec))
     return spectral_normalize_torch(torch.matmul(basis, spec))
 
 
 def mel_spectrogram_torch(y, n_fft, num_mels, sampling_rate, hop_size, win_size, fmin, fmax, center=False):
     # reference mel_processing.py:85-112 (computes in fp32: `y.float()` at :104)
     spec = spectrogram_torch(y.float(), n_fft, sampling_rate, hop_size, win_size, center)
-    basis = _basis(sampling_rate, n_fft, num_mels, fmin, fmax, spec.dtype, spec.device)
-    return spectral_normalize_torch(torch.matmul(basis, spec))
+    return _mel(spec, _basis(sampling_rate, n_fft, num_mels, fmin, fmax, spec.dtype, spec.device))

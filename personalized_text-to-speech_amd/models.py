@@ -565,7 +565,11 @@ class SynthesizerTrn(nn.Module):
 
     @staticmethod
     def neg_cent(z_p, m_p, logs_p):
-        """Negative cross-entropy of every (frame, token) pair (models.py:470-477), fp32."""
+        """Negative cross-entropy of every (frame, token) pair (models.py:470-477), fp32 — also inside an autocast region:
+        this tensor feeds the discrete alignment DP, and bf16 products (errors ~0.5 on values ~100) change paths."""
+        if z_p.is_cuda and torch.is_autocast_enabled():
+            with torch.autocast("cuda", enabled=False):
+                return SynthesizerTrn.neg_cent(z_p, m_p, logs_p)
         z_p, m_p, logs_p = z_p.float(), m_p.float(), logs_p.float()
         s_p_sq_r = torch.exp(-2 * logs_p)                                              # [b, d, t_s]
         neg_cent1 = torch.sum(-0.5 * commons.LOG_2PI - logs_p, [1], keepdim=True)      # [b, 1, t_s]

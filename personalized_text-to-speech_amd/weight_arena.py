@@ -108,6 +108,10 @@ class WeightArena:
                         for o, s in zip(offs, specs)]
         self.dws = [cview(self.dw, o, s) if s.groups > 1 else view(self.dw, o, s, s.fwd_shape) for o, s in zip(offs, specs)]
         self.ptrs = [p.data_ptr() for p in self.params]
+        # Every forward overwrites the shared operand / gradient buffers.  `gen` counts forwards, `claimed` the weight-gradient
+        # slots written since the last forward: PrepFn.backward refuses to hand out gradients computed from operands a later
+        # forward has overwritten, and a slot written twice in one backward (a module used twice in one graph) is refused too.
+        self.gen, self.claimed = 0, set()
         for i, h in enumerate(self.handles):
             _registry[h.data_ptr()] = (self, i)
 
@@ -134,6 +138,9 @@ class PrepFn(torch.autograd.Function):
     def forward(ctx, arena, *params):
         if arena.defer is not None:
             arena.defer.flush()                      # leftovers of a backward that never reached this node
+        arena.gen += 1
+        arena.claimed.clear()
+        ctx.gen = arena.gen
         rc = _lib.lib().vits_weight_prep(arena.table.data_ptr(), arena.n, arena.total_rows, _DT[arena.dtype],
                                          arena.w_fwd.data_ptr(), arena.w_bwd.data_ptr(), _lib.stream_ptr())
         _lib.check(rc, "vits_weight_prep")
@@ -147,8 +154,20 @@ class PrepFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *dws):
         arena = ctx.arena
+        if ctx.gen != arena.gen:
+            raise RuntimeError(
+                "weight_arena: this backward belongs to forward #%d, but forward #%d has since overwritten the arena's shared "
+                "operands and gradient buffers (two forwards of one network before a backward, e.g. loss(net(a)) + loss(net(b))): "
+                "run each forward's backward before the next forward, or batch the inputs" % (ctx.gen, arena.gen))
         if arena.defer is not None:
             arena.defer.flush()                      # the deferred second stages of this network's weight-gradient launches
+        arena.claimed.clear()
+        # gradient accumulation (no zero_grad between two backwards): a param.grad that still aliases `dparam` would be
+        # overwritten below and then added to itself by autograd — detach it into its own storage first
+        base = arena.dparam.untyped_storage().data_ptr()
+        for p in arena.params:
+            if p.grad is not None and p.grad.untyped_storage().data_ptr() == base:
+                p.grad = p.grad.clone()
         for i, d in enumerate(dws):
             if d is None:
                 arena.dws[i].zero_()
@@ -165,10 +184,21 @@ class PrepFn(torch.autograd.Function):
 class Resolved:
     """What a layer node needs for one convolution weight (`defer`: the arena's collector of weight-gradient second stages,
     run in one launch right before the arena maps the weight gradients back to parameter gradients)."""
-    __slots__ = ("fwd", "bwd", "dw", "defer")
+    __slots__ = ("fwd", "bwd", "dw", "defer", "arena", "index")
 
-    def __init__(self, fwd, bwd, dw, defer=None):
-        self.fwd, self.bwd, self.dw, self.defer = fwd, bwd, dw, defer
+    def __init__(self, fwd, bwd, dw, defer=None, arena=None, index=-1):
+        self.fwd, self.bwd, self.dw, self.defer, self.arena, self.index = fwd, bwd, dw, defer, arena, index
+
+    def claim_dw(self):
+        """The arena's weight-gradient view for this convolution (None outside an arena), claimed for the current backward:
+        a second claim before the arena's own backward means the same weight is used twice in one graph, and autograd would
+        sum the one shared view with itself."""
+        if self.arena is not None:
+            if self.index in self.arena.claimed:
+                raise RuntimeError("weight_arena: a convolution weight is used twice in one autograd graph; the arena keeps one "
+                                   "gradient buffer per weight (call the module once per forward, or outside weight_arena.scope)")
+            self.arena.claimed.add(self.index)
+        return self.dw
 
 
 _constants = {}            # data_ptr -> Resolved, for constant operands registered with register_constant()
@@ -189,7 +219,7 @@ def resolve(w, dtype):
     hit = _registry.get(w.data_ptr())
     if hit is not None and hit[0].dtype == dtype and tuple(w.shape) == tuple(hit[0].handles[hit[1]].shape):
         a, i = hit
-        return Resolved(a.fwd[i], a.bwd[i], a.dws[i], a.defer)
+        return Resolved(a.fwd[i], a.bwd[i], a.dws[i], a.defer, a, i)
     wd = w.detach().to(dtype)
     return Resolved(wd, None, None)
 

@@ -76,7 +76,7 @@ class ConvCLFn(torch.autograd.Function):
             if want_db and dy.size(2) % 8 == 0:
                 db = torch.empty(dy.size(2), dtype=torch.float32, device=dy.device)
             dw = K.conv1d_cl_wgrad_raw(xd, dy, k, lengths=ctx.lengths, dil=dil, pad=pad, stride=stride, in_slope=in_slope,
-                                       flags=K.CONV_MASK_IN if mask_in else 0, out=R.dw, dbias=db, groups=ctx.groups,
+                                       flags=K.CONV_MASK_IN if mask_in else 0, out=R.claim_dw(), dbias=db, groups=ctx.groups,
                                        defer=R.defer if R.dw is not None else None)
         if want_db and db is None:
             db = K.colsum(dy)
@@ -204,11 +204,11 @@ class WNFn(torch.autograd.Function):
             last = i == L - 1
             dy_rs = d_o if last else dcat
             db_rs = torch.empty(H if last else 2 * H, dtype=torch.float32, device=d_out.device)
-            grads[4 * i + 2] = WG(acts, dy_rs, 1, out=r_rs.dw, dbias=db_rs, defer=defer)
+            grads[4 * i + 2] = WG(acts, dy_rs, 1, out=r_rs.claim_dw(), dbias=db_rs, defer=defer)
             grads[4 * i + 3] = db_rs
             d_pre = C(dy_rs, WA.bwd_operand(r_rs), None, mg_src=pre, lengths=lengths, flags=K.CONV_GATE_BWD | K.CONV_MASK_OUT, gate_h=H)
             db_in = torch.empty(2 * H, dtype=torch.float32, device=d_out.device)
-            grads[4 * i] = WG(h, d_pre, k, dil=d, pad=pad, out=r_in.dw, dbias=db_in, defer=defer)
+            grads[4 * i] = WG(h, d_pre, k, dil=d, pad=pad, out=r_in.claim_dw(), dbias=db_in, defer=defer)
             grads[4 * i + 1] = db_in
             if dcond is not None:
                 dcond.append(K.colsum(d_pre, per_item=True))              # [b, 2H]: gradient of cond[i]

@@ -48,3 +48,42 @@ def test_whole_model_through_arena_matches_reference(emulated):
     with torch.no_grad(), pkg.rng.noise.replay(noise_list(g, "infer")):
         o_i = net.infer(x, xl, sid, noise_scale=0.667, length_scale=1.1, noise_scale_w=0.8)[0]
     assert rel_err(o_i, g["infer/o"]) < 2e-5 and net._weight_arenas[torch.float32] is arena
+
+
+def _probe(pkg, net, g, scale=1.0):
+    x, xl, spec, sl, sid = inputs(g)
+    with pkg.rng.noise.replay(noise_list(g, "fwd")):
+        o, l_length, attn, ids, xm, ym, (z, z_p, m_p, logs_p, m_q, logs_q) = net(x, xl, spec * scale, sl, sid)
+    return o.pow(2).mean() + l_length.sum() + pkg.losses.kl_loss(z_p, logs_q, m_p, logs_p, ym)
+
+
+def test_backward_after_a_second_forward_is_refused(emulated):
+    """The arena's operand / gradient buffers are shared by every forward: loss(net(a)) + loss(net(b)) would silently compute
+    the first forward's gradients from the second one's operands — it must raise instead."""
+    pkg = emulated
+    g, cfg = load_tiny()
+    net = build_tiny(pkg, g, cfg)
+    p1 = _probe(pkg, net, g)
+    p2 = _probe(pkg, net, g, scale=0.5)
+    with pytest.raises(RuntimeError, match="weight_arena"):
+        (p1 + p2).backward()
+
+
+def test_gradient_accumulation_without_zero_grad(emulated):
+    """param.grad views alias the arena's gradient buffer; a second backward without zero_grad must ADD to the first
+    gradient, not overwrite-and-double."""
+    pkg = emulated
+    g, cfg = load_tiny()
+    net = build_tiny(pkg, g, cfg)
+    net.zero_grad()
+    _probe(pkg, net, g).backward()
+    first = {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+    _probe(pkg, net, g, scale=0.5).backward()
+    second_only = build_tiny(pkg, g, cfg)
+    second_only.zero_grad()
+    _probe(pkg, second_only, g, scale=0.5).backward()
+    ref = dict(second_only.named_parameters())
+    for k in ["enc_q.enc.in_layers.3.weight_v", "dec.ups.1.weight_g", "flow.flows.2.post.weight", "enc_q.pre.weight"]:
+        want = first[k] + ref[k].grad
+        got = dict(net.named_parameters())[k].grad
+        assert rel_err(got, want) < 1e-5, k

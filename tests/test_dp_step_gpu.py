@@ -1,0 +1,115 @@
+"""GPU: the data-parallel form of the fine-tune step with world_size 2 (reference finetune_speaker_v2.py:69,144-145 — two
+DistributedDataParallel wrappers; here distributed.GradBuckets + train.FineTuner.capture_segments).
+
+Two fresh child processes share the test box's one GPU over the gloo backend (tests/dp_child.py).  Checked:
+  * both ranks end with identical parameters (captured three-graph form AND eager hook form);
+  * those parameters equal an in-process emulation: two replicas stepping in lock step on the two ranks' minibatches with
+    their gradients averaged by hand at the two exchange points (after the D backward, after the G backward);
+  * bench.py's N > 1 branch (capture -> agreed flag -> verify_replay -> agreed flag) runs end to end with 2 ranks.
+fp32 parity mode, dropout off; tolerance 1e-5 relative (same kernels, same order; only the averaging differs in form)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _run_children(tmp_path, mode):
+    port = _port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    outs = [str(tmp_path / f"{mode}_rank{r}.npz") for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dp_child.py"), str(r), "2", str(port), outs[r], mode],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=420)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("data-parallel child ranks timed out")
+        logs.append(o)
+    assert all(p.returncode == 0 for p in procs), "\n".join(l[-3000:] for l in logs)
+    return [np.load(o) for o in outs]
+
+
+def _reference(pkg):
+    """Two replicas in this process, gradients averaged by hand at the two exchange points."""
+    sys.path.insert(0, HERE)
+    import dp_child as C
+    from importlib import import_module
+    cfgs = import_module("personalized_text-to-speech_amd.configs")
+    tr = import_module("personalized_text-to-speech_amd.train")
+    g = np.load(os.path.join(ROOT, "tests", "golden", "step_tiny.npz"))
+    cfg = json.loads(bytes(g["config"]).decode())
+    fts = [C.make_tuner(pkg, cfgs, tr, g, cfg) for _ in range(2)]
+    batches = [C.make_batch(pkg, cfg, r) for r in range(2)]
+
+    def average(nets):
+        for ps in zip(*[n.parameters() for n in nets]):
+            gs = [p.grad for p in ps]
+            if all(x is None for x in gs):
+                continue
+            avg = sum(x.detach().clone() if x is not None else torch.zeros_like(ps[0]) for x in gs) / len(gs)
+            for p in ps:
+                p.grad = avg.clone()
+
+    for i in range(3):
+        for ft, b in zip(fts, batches):
+            torch.manual_seed(1000 + i)
+            ft._phase_a(b)
+        average([ft.net_d for ft in fts])
+        for ft in fts:
+            ft._phase_b()
+        average([ft.net_g for ft in fts])
+        for ft in fts:
+            ft._phase_c()
+    torch.cuda.synchronize()
+    return fts[0]
+
+
+def _close(a, b, tol=1e-5):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.all(np.abs(a - b) <= tol * np.maximum(np.abs(b), 1e-3))
+
+
+@pytest.mark.parametrize("mode", ["graph", "eager"])
+def test_two_ranks_match_emulation(pkg, tmp_path, mode):
+    r0, r1 = _run_children(tmp_path, mode)
+    for k in r0.files:
+        if k != "losses":
+            assert np.array_equal(r0[k], r1[k]), f"ranks disagree on {k}"
+    assert not np.array_equal(r0["losses"], r1["losses"])          # different data per rank
+    ref = _reference(pkg)
+    for tag, net in (("g", ref.net_g), ("d", ref.net_d)):
+        ps = dict(net.named_parameters())
+        assert _close(r0[f"abs_{tag}"], [float(p.detach().double().abs().sum()) for p in ps.values()]), tag
+        for k in [k for k in r0.files if k.startswith(f"p_{tag}/")]:
+            want = ps[k[4:]].detach().cpu().numpy()
+            assert np.abs(r0[k] - want).max() <= 1e-5 * max(np.abs(want).max(), 1e-3), k
+
+
+def test_bench_two_ranks_one_device():
+    """bench.py's N = 2 branch on one device: capture_segments, both agreed flags, verify_replay, timed replays, JSON line."""
+    env = dict(os.environ, VITS_BENCH_ONE_DEVICE="1", VITS_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "C1"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2"
+    assert "three hipGraphs" in line["config"]["execution"], line["config"]["execution"] + res.stderr[-2000:]

@@ -127,3 +127,45 @@ def test_mel_basis_shape_and_norm():
     b = O.mel_basis_slaney(22050, 1024, 80, 0.0, None)
     assert tuple(b.shape) == (80, 513) and b.dtype == torch.float32 and (b >= 0).all()
     assert (b.sum(1) > 0).all() and float(b[0, 0]) == 0.0
+
+
+def test_step_losses_and_gradients_match_reference_step(pkg):
+    """The oracle's restatement of one fine-tune iteration (train_losses + generator_losses around two AdamW updates,
+    reference finetune_speaker_v2.py:174-232) against tests/golden/step_tiny.npz, produced by driving the reference's own
+    modules, losses and optimizers (tools/gen_golden_step.py).  Pins the CPU baseline's step and the D-before-G ordering."""
+    import json
+    g = np.load(os.path.join(ROOT, "tests", "golden", "step_tiny.npz"))
+    cfg = json.loads(bytes(g["config"]).decode())
+    sd_g = {k[3:]: torch.from_numpy(g[k]).clone() for k in g.files if k.startswith("sd/")}
+    for v in sd_g.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    torch.manual_seed(cfg["d_seed"])
+    d = pkg.MultiPeriodDiscriminator(False)
+    assert np.allclose([float(p.detach().double().sum()) for p in d.parameters()], g["d/param_checksum"], rtol=1e-6, atol=1e-6)
+    sd_d = {k: v.detach().clone().requires_grad_(True) for k, v in d.state_dict().items()}
+    t = lambda k: torch.from_numpy(g["in/" + k])
+    batch = (t("x"), t("x_lengths"), t("spec"), t("spec_lengths"), t("y"), t("y_lengths"), t("sid"))
+    noise = [torch.from_numpy(g[f"noise{i}"]) for i in range(int(g["n_noise"]))]
+    hp = dict(cfg["data"]); hp.update(cfg["train"])
+    kw = dict(betas=hp["betas"], eps=hp["eps"])
+    opt_g = torch.optim.AdamW([v for v in sd_g.values() if v.requires_grad], hp["learning_rate"], **kw)
+    opt_d = torch.optim.AdamW(list(sd_d.values()), hp["learning_rate"], **kw)
+    loss_disc, rest = O.train_losses(sd_g, sd_d, cfg["model"], hp, batch, noise)
+    opt_d.zero_grad(); loss_disc.backward()
+    gn_d = torch.sqrt(sum(v.grad.double().pow(2).sum() for v in sd_d.values()))
+    for k in [k for k in g.files if k.startswith("grad_d/")]:
+        assert rel_err(sd_d[k[7:]].grad, g[k]) < 1e-4, k
+    opt_d.step()
+    loss_gen_all, parts = O.generator_losses(sd_d, hp, *rest)
+    opt_g.zero_grad(); loss_gen_all.backward()
+    gn_g = torch.sqrt(sum(v.grad.double().pow(2).sum() for v in sd_g.values() if v.grad is not None))
+    got = dict(loss_disc=loss_disc, grad_norm_d=gn_d, grad_norm_g=gn_g, **parts)
+    for k, v in got.items():
+        ref = float(g["out/" + k])
+        assert abs(float(v) - ref) <= 1e-4 * abs(ref), (k, float(v), ref)
+    for k in [k for k in g.files if k.startswith("grad_g/")]:
+        assert rel_err(sd_g[k[7:]].grad, g[k]) < 1e-4, k
+    opt_g.step()
+    for k in [k for k in g.files if k.startswith("new_g/")]:
+        assert rel_err(sd_g[k[6:]], g[k]) < 1e-4, k

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Which tensors differ between two replays of the captured step from the same state?  (verify_replay's diagnosis tool.)"""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+from importlib import import_module
+P = import_module("personalized_text-to-speech_amd"); cfgs = import_module("personalized_text-to-speech_amd.configs"); tr = import_module("personalized_text-to-speech_amd.train")
+cfg_name, batch_size, t_y_range = cfgs.WORKLOADS[os.environ.get("WL", "C2")]
+hps = cfgs.get(cfg_name)
+ft = tr.FineTuner(hps, "cuda:0", amp=os.environ.get("FP32") != "1")
+batch = tr.synthetic_batch(hps, batch_size, t_y_range, "cuda:0")
+ft.capture(batch, warmup=3)
+ts = ft._state_tensors()
+snap = [t.detach().clone() for t in ts]
+rng = torch.cuda.get_rng_state(ft.device)
+named = [("G." + k, p) for k, p in ft.net_g.named_parameters()] + [("D." + k, p) for k, p in ft.net_d.named_parameters()]
+
+def run(fn):
+    with torch.no_grad():
+        for t, s in zip(ts, snap):
+            t.copy_(s)
+    torch.cuda.set_rng_state(rng, ft.device)
+    out = fn()
+    torch.cuda.synchronize()
+    res = {"out." + k: v.detach().clone() for k, v in out.items()}
+    for k, p in named:
+        res["param." + k] = p.detach().clone()
+        if p.grad is not None:
+            res["grad." + k] = p.grad.detach().clone()
+    return res
+
+runs = [run(ft.replay) for _ in range(3)] + [run(lambda: ft.step(batch))]
+for i, name in ((1, "replay2"), (2, "replay3"), (3, "eager")):
+    diff = []
+    for k in runs[0]:
+        if k in runs[i] and not torch.equal(runs[0][k], runs[i][k]):
+            a, b = runs[0][k].double(), runs[i][k].double()
+            diff.append((float((a - b).abs().max() / (b.abs().max() + 1e-30)), k))
+    diff.sort(reverse=True)
+    print(f"--- replay1 vs {name}: {len(diff)} of {len(runs[0])} tensors differ")
+    kinds = {}
+    for d, k in diff:
+        kk = k.split(".")[0] + "." + k.split(".")[1]
+        kinds[kk] = kinds.get(kk, 0) + 1
+    print("   by kind:", kinds)
+    for d, k in diff[:25]:
+        print(f"   {d:.3e}  {k}")
+    outs = {k: (float(runs[0][k]), float(runs[i][k])) for k in runs[0] if k.startswith("out.")}
+    print("   out:", {k: v for k, v in outs.items() if v[0] != v[1]})

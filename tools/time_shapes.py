@@ -19,5 +19,5 @@ for name, sm in P._lib.timer.summary().items():
     rows.append((sm["total_ms"] / 3, sm["calls"] / 3, sm["avg_ms"] * 1e3, fl / (sm["total_ms"] * 1e-3) / 1e12, by / (sm["total_ms"] * 1e-3) / 1e9, name))
 rows.sort(reverse=True)
 print(f"{'ms/step':>8} {'calls':>6} {'avg_us':>8} {'TFLOP/s':>8} {'GB/s':>8}  kernel shape")
-for r in rows[:45]:
+for r in rows[:int(os.environ.get("TOPN", "45"))]:
     print(f"{r[0]:8.3f} {r[1]:6.1f} {r[2]:8.1f} {r[3]:8.1f} {r[4]:8.1f}  {r[5]}")
