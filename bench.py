@@ -131,8 +131,12 @@ def main():
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             return int(flag) == 1
 
-        for _ in range(3):
-            tuner.step(batch)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                tuner.step(batch)
+        torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         why = None
         try:

@@ -80,13 +80,13 @@ class MultiHeadAttention(nn.Module):
     def forward_cl(self, h, attn_mask, lengths, res=None):
         """h [b, t, c] channels-last -> conv_o(attention(h)) (+ res), 1x1 projections on the MFMA kernel."""
         from . import wn_cl
-        q = wn_cl.conv_cl(h, wn_cl.weight_of(self.conv_q), self.conv_q.bias)
-        k = wn_cl.conv_cl(h, wn_cl.weight_of(self.conv_k), self.conv_k.bias)
-        v = wn_cl.conv_cl(h, wn_cl.weight_of(self.conv_v), self.conv_v.bias)
+        q = wn_cl.conv_cl(h, wn_cl.weight_of(self.conv_q), wn_cl.bias_of(self.conv_q))
+        k = wn_cl.conv_cl(h, wn_cl.weight_of(self.conv_k), wn_cl.bias_of(self.conv_k))
+        v = wn_cl.conv_cl(h, wn_cl.weight_of(self.conv_v), wn_cl.bias_of(self.conv_v))
         from . import attention_cl
         o, self.attn = attention_cl.rel_attention_cl(q, k, v, self.emb_rel_k, self.emb_rel_v, lengths, self.n_heads,
                                                      self.window_size, self.p_dropout, self.training, q.dtype)
-        return wn_cl.conv_cl(o, wn_cl.weight_of(self.conv_o), self.conv_o.bias, res=res)
+        return wn_cl.conv_cl(o, wn_cl.weight_of(self.conv_o), wn_cl.bias_of(self.conv_o), res=res)
 
 
 class FFN(nn.Module):
@@ -113,11 +113,11 @@ class FFN(nn.Module):
         (attentions.py:277-293): mask-in / ReLU are prologues, mask-out / residual epilogues of the two convolutions."""
         from . import wn_cl
         pad = (self.kernel_size - 1) // 2
-        y = wn_cl.conv_cl(h, wn_cl.weight_of(self.conv_1), self.conv_1.bias, lengths, pad=pad, mask_in=True)
+        y = wn_cl.conv_cl(h, wn_cl.weight_of(self.conv_1), wn_cl.bias_of(self.conv_1), lengths, pad=pad, mask_in=True)
         if self.training and self.p_dropout > 0:
             y = self.drop(torch.relu(y))
-            y = wn_cl.conv_cl(y, wn_cl.weight_of(self.conv_2), self.conv_2.bias, lengths, pad=pad, mask_in=True, mask_out=True)
+            y = wn_cl.conv_cl(y, wn_cl.weight_of(self.conv_2), wn_cl.bias_of(self.conv_2), lengths, pad=pad, mask_in=True, mask_out=True)
             return y if res is None else y + res
         if res is not None:     # (conv * mask) + res: res rows beyond the length are zero in the encoder, so masking the sum is exact
-            return wn_cl.conv_cl(y, wn_cl.weight_of(self.conv_2), self.conv_2.bias, lengths, pad=pad, in_slope=0.0, mask_in=True, mask_out=True, res=res)
-        return wn_cl.conv_cl(y, wn_cl.weight_of(self.conv_2), self.conv_2.bias, lengths, pad=pad, in_slope=0.0, mask_in=True, mask_out=True)
+            return wn_cl.conv_cl(y, wn_cl.weight_of(self.conv_2), wn_cl.bias_of(self.conv_2), lengths, pad=pad, in_slope=0.0, mask_in=True, mask_out=True, res=res)
+        return wn_cl.conv_cl(y, wn_cl.weight_of(self.conv_2), wn_cl.bias_of(self.conv_2), lengths, pad=pad, in_slope=0.0, mask_in=True, mask_out=True)

@@ -46,11 +46,21 @@ def weight_norm(v, g):
     return (v.float() * (g.float() / norm)).to(v.dtype)
 
 
+def _no_library_conv(x):
+    if x.is_cuda:
+        raise RuntimeError("library convolution reached on a GPU tensor: every convolution of the hot path runs through "
+                           "libvitsmi.so (wn_cl.conv_cl / decoder_cl / disc_cl); generic nn.Module calls are CPU-side utilities only")
+
+
 def conv1d(x, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
+    """Generic module call (state_dict / shape utilities on the CPU).  Raises on GPU tensors: nothing on the hot path may
+    fall back to MIOpen (its bf16 backward-data solver for c_in = 1 faults on gfx950 / ROCm 7.2)."""
+    _no_library_conv(x)
     return F.conv1d(x, weight.to(x.dtype), None if bias is None else bias.to(x.dtype), stride, padding, dilation, groups)
 
 
 def conv_transpose1d(x, weight, bias=None, stride=1, padding=0):
+    _no_library_conv(x)
     return F.conv_transpose1d(x, weight.to(x.dtype), None if bias is None else bias.to(x.dtype), stride, padding)
 
 

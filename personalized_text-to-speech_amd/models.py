@@ -4,8 +4,6 @@ tuples, so checkpoints and callers are interchangeable.  File:line citations poi
 """
 import math
 
-import os
-
 import torch
 from torch import nn
 from torch.nn import functional as F
@@ -56,11 +54,11 @@ class StochasticDurationPredictor(nn.Module):
         dtype = wn_cl.compute_dtype()
         lengths = wn_cl.lengths_of(x_mask)
         m = x_mask.transpose(1, 2)                                     # [b, t, 1]
-        xc = wn_cl.conv_cl(torch.detach(x).transpose(1, 2).contiguous(), wn_cl.weight_of(self.pre), self.pre.bias, dtype=dtype)
+        xc = wn_cl.conv_cl(torch.detach(x).transpose(1, 2).contiguous(), wn_cl.weight_of(self.pre), wn_cl.bias_of(self.pre), dtype=dtype)
         if g is not None:
             xc = xc + self.cond(torch.detach(g)).transpose(1, 2).to(dtype)
         xc = self.convs.forward_cl(xc, lengths, m)
-        xc = wn_cl.conv_cl(xc, wn_cl.weight_of(self.proj), self.proj.bias, lengths, mask_out=True, dtype=dtype)
+        xc = wn_cl.conv_cl(xc, wn_cl.weight_of(self.proj), wn_cl.bias_of(self.proj), lengths, mask_out=True, dtype=dtype)
 
         def run(flow, z, cond):
             if isinstance(flow, modules.Flip):
@@ -76,9 +74,9 @@ class StochasticDurationPredictor(nn.Module):
         if not reverse:
             assert w is not None
             w_cl = w.transpose(1, 2).float()                           # [b, t, 1]
-            h_w = wn_cl.conv_cl(F.pad(w_cl, (0, 7)).to(dtype), wn_cl.weight_of(self.post_pre, pad_in=7), self.post_pre.bias, dtype=dtype)
+            h_w = wn_cl.conv_cl(F.pad(w_cl, (0, 7)).to(dtype), wn_cl.weight_of(self.post_pre, pad_in=7), wn_cl.bias_of(self.post_pre), dtype=dtype)
             h_w = self.post_convs.forward_cl(h_w, lengths, m)
-            h_w = wn_cl.conv_cl(h_w, wn_cl.weight_of(self.post_proj), self.post_proj.bias, lengths, mask_out=True, dtype=dtype)
+            h_w = wn_cl.conv_cl(h_w, wn_cl.weight_of(self.post_proj), wn_cl.bias_of(self.post_proj), lengths, mask_out=True, dtype=dtype)
             e_q = noise.randn(w.size(0), 2, w.size(2), device=x.device, dtype=torch.float32).transpose(1, 2) * m
             z_q, logdet_tot_q = e_q, 0
             cond_q = xc + h_w
@@ -125,12 +123,22 @@ class DurationPredictor(nn.Module):
             self.cond = Conv1d(gin_channels, in_channels, 1)
 
     def forward(self, x, x_mask, g=None):
+        """models.py:120-132 on the channels-last kernels: masked k-tap convolutions with ReLU as the next kernel's input
+        activation... (ReLU sits BEFORE the LayerNorm here, so it is applied by the row kernel's caller instead)."""
+        from . import rowops, wn_cl
+        dtype = wn_cl.compute_dtype()
+        lengths = wn_cl.lengths_of(x_mask)
         x = torch.detach(x)
         if g is not None:
             x = x + self.cond(torch.detach(g))
-        x = self.drop(self.norm_1(torch.relu(self.conv_1(x * x_mask))))
-        x = self.drop(self.norm_2(torch.relu(self.conv_2(x * x_mask))))
-        return self.proj(x * x_mask) * x_mask
+        h = x.transpose(1, 2).to(dtype).contiguous()
+        pad = self.kernel_size // 2
+        for conv, norm in ((self.conv_1, self.norm_1), (self.conv_2, self.norm_2)):
+            h = wn_cl.conv_cl(h, wn_cl.weight_of(conv), wn_cl.bias_of(conv), lengths, pad=pad, mask_in=True, dtype=dtype)
+            h = self.drop(rowops.ln_act(torch.relu(h), norm.gamma, norm.beta, None, norm.eps, 0))
+        cpad = (-1) % 8
+        y = wn_cl.conv_cl(h, wn_cl.weight_of(self.proj, pad_out=cpad), wn_cl.bias_of(self.proj, cpad), lengths, mask_in=True, mask_out=True, dtype=dtype)
+        return y[..., :1].transpose(1, 2).to(x.dtype)
 
 
 class _EmbeddingScaledFn(torch.autograd.Function):
@@ -178,7 +186,9 @@ class TextEncoder(nn.Module):
         x = torch.transpose(x, 1, -1)                             # [b, h, t]
         x_mask = torch.unsqueeze(commons.sequence_mask(x_lengths, x.size(2)), 1).to(x.dtype)
         x = self.encoder(x * x_mask, x_mask)
-        stats = self.proj(x) * x_mask
+        from . import wn_cl                    # 1x1 projection on the channels-last MFMA kernel, `* x_mask` as its epilogue
+        stats = wn_cl.conv_cl(x.transpose(1, 2).contiguous(), wn_cl.weight_of(self.proj), wn_cl.bias_of(self.proj),
+                              x_lengths.to(torch.int32), mask_out=True).transpose(1, 2)
         m, logs = torch.split(stats, self.out_channels, dim=1)
         return x, m, logs, x_mask
 
@@ -236,9 +246,9 @@ class PosteriorEncoder(nn.Module):
         cin = self.in_channels
         cpad = (-cin) % 8
         x_cl = torch.nn.functional.pad(x.transpose(1, 2), (0, cpad)).to(dtype).contiguous()
-        h = wn_cl.conv_cl(x_cl, wn_cl.weight_of(self.pre, pad_in=cpad), self.pre.bias, lengths, mask_out=True)
+        h = wn_cl.conv_cl(x_cl, wn_cl.weight_of(self.pre, pad_in=cpad), wn_cl.bias_of(self.pre), lengths, mask_out=True)
         h = wn_cl.wn_forward_cl(self.enc, h, lengths, g)
-        stats = wn_cl.conv_cl(h, wn_cl.weight_of(self.proj), self.proj.bias, lengths, mask_out=True).float()
+        stats = wn_cl.conv_cl(h, wn_cl.weight_of(self.proj), wn_cl.bias_of(self.proj), lengths, mask_out=True).float()
         m, logs = stats[..., :self.out_channels], stats[..., self.out_channels:]
         z = (m + noise.randn_like(m.transpose(1, 2)).transpose(1, 2) * torch.exp(logs)) * x_mask.transpose(1, 2)
         return z.transpose(1, 2), m.transpose(1, 2), logs.transpose(1, 2), x_mask
@@ -288,18 +298,6 @@ class Generator(nn.Module):
             l.remove_weight_norm()
 
 
-def _first_layer_fp32(layer, x):
-    """The single-input-channel first convolution of each discriminator runs in fp32 even under
-    bf16 autocast: MIOpen's bf16 backward-data solver for c_in = 1 (e.g. `convbfp16 -n 32 -c 1 -W 8192
-    -k 16 -x 15 -F 2`) faults on gfx950/ROCm 7.2 from its third invocation on (found with
-    MIOPEN_ENABLE_LOGGING_CMD=1 + AMD_SERIALIZE_KERNEL=3).  With one input channel the layer is
-    <0.1 % of the discriminator's FLOPs, and fp32 is at least the reference's precision."""
-    if torch.is_autocast_enabled():
-        with torch.autocast("cuda", enabled=False):
-            return layer(x.float())
-    return layer(x)
-
-
 class _WNConv2dK1(nn.Module):
     """weight_norm(Conv2d(cin, cout, (k,1), (s,1), padding=(p,0))) of DiscriminatorP (models.py:304-312);
     parameters `bias`, `weight_g` [cout,1,1,1], `weight_v` [cout,cin,k,1]."""
@@ -320,11 +318,7 @@ class _WNConv2dK1(nn.Module):
         return K.weight_norm(self.weight_v, self.weight_g).squeeze(-1)
 
     def forward(self, x):
-        from . import weight_arena
-        w = weight_arena.handle_for(self, "torch")
-        if w is None:
-            w = K.weight_norm(self.weight_v, self.weight_g)
-        return F.conv2d(x, w.to(x.dtype), self.bias.to(x.dtype), self.stride, self.padding)
+        return F.conv2d(x, K.weight_norm(self.weight_v, self.weight_g).to(x.dtype), self.bias.to(x.dtype), self.stride, self.padding)
 
 
 class _Fmaps(list):
@@ -334,6 +328,20 @@ class _Fmaps(list):
     def __init__(self):
         super().__init__()
         self.cl, self.den = [], []
+
+
+def _disc_outputs(period, n, y8, hs):
+    """(logits [n, t'*p], feature maps in the reference's layout) from one discriminator's channels-last results."""
+    fmap = _Fmaps()
+    for h in hs:
+        # P: [(n, w), t', c] -> view [n, c, t', period];  S: [n, t, c] -> view [n, c, t]
+        fmap.append(h.view(n, period, h.size(1), h.size(2)).permute(0, 3, 2, 1) if period > 1 else h.transpose(1, 2))
+        fmap.cl.append(h); fmap.den.append(h.numel() // 2)
+    y = y8[..., :1]                                                          # channels 1..7 are exactly zero
+    y = y.reshape(n, period, y.size(1), 1).permute(0, 3, 2, 1) if period > 1 else y.transpose(1, 2)
+    fmap.append(y)
+    fmap.cl.append(y8); fmap.den.append(y.numel() // 2)
+    return torch.flatten(y, 1, -1), fmap
 
 
 class DiscriminatorP(nn.Module):
@@ -351,73 +359,22 @@ class DiscriminatorP(nn.Module):
             _WNConv2dK1(1024, 1024, kernel_size, 1, p)])
         self.conv_post = _WNConv2dK1(1024, 1, 3, 1, 1)
 
-    # HIP path: the flat-row kernels (csrc/conv1d_flat.hip, FLAT weight gradient) tile the joint (item, time) index,
-    # which is what these shapes need (deep layers have 10-51 rows per folded batch element).  VITS_DISC_P=library
-    # selects the MIOpen convolutions instead (A/B measurements only).
-    use_hip = os.environ.get("VITS_DISC_P", "hip") != "library"
-
     def forward(self, x):
-        return self.forward_hip(x) if DiscriminatorP.use_hip else self.forward_rocm(x)
-
-    def forward_rocm(self, x):
-        fmap = []
-        b, c, t = x.shape
-        if t % self.period != 0:                                   # pad first (models.py:319-322)
-            n_pad = self.period - (t % self.period)
-            x = F.pad(x, (0, n_pad), "reflect")
-            t = t + n_pad
-        x = x.view(b, c, t // self.period, self.period)
-        for i, l in enumerate(self.convs):
-            x = F.leaky_relu(_first_layer_fp32(l, x) if i == 0 else l(x), modules.LRELU_SLOPE)
-            fmap.append(x)
-        x = self.conv_post(x)
-        fmap.append(x)
-        return torch.flatten(x, 1, -1), fmap
+        return self.forward_hip(x)
 
     def forward_hip(self, x):
-        """x [n, 1, t] -> (logits [n, t'], fmap list in the reference's [n, c, t', period] layout).
-        The (k, 1) convolutions act along t' only, so the period axis is folded into the batch and the five
-        layers run as strided channels-last 1-D convolutions on the MFMA kernel, leaky-relu fused as epilogue."""
-        from . import wn_cl
-        dtype = wn_cl.compute_dtype()
-        fmap = _Fmaps()
-        n, c, t = x.shape
-        p_ = self.period
-        if t % p_ != 0:                                             # pad first (models.py:319-322)
-            n_pad = p_ - (t % p_)
-            x = F.pad(x, (0, n_pad), "reflect")
-            t = t + n_pad
-        rows = t // p_
-        h = x.view(n, rows, p_).transpose(1, 2).reshape(n * p_, rows, 1)                  # [(n, w), t', 1]
-        h = F.pad(h, (0, 7)).to(dtype)                                                    # c_in 1 -> 8 (vector width), zero weights there
-        for i, l in enumerate(self.convs):
-            w = wn_cl.weight_of(l, pad_in=7 if i == 0 else 0)
-            h = wn_cl.conv_cl(h, w, l.bias, pad=l.padding[0], stride=l.stride[0], out_slope=modules.LRELU_SLOPE, dtype=dtype)
-            fmap.append(h.view(n, p_, h.size(1), h.size(2)).permute(0, 3, 2, 1))          # [n, c, t', period] view
-            fmap.cl.append(h); fmap.den.append(h.numel() // 2)
-        l = self.conv_post
-        y8 = wn_cl.conv_cl(h, wn_cl.weight_of(l, pad_out=7), wn_cl.bias_of(l, 7), pad=l.padding[0], dtype=dtype)
-        y = y8[..., :1]                                                                   # channels 1..7 are exactly zero
-        y = y.reshape(n, p_, y.size(1), 1).permute(0, 3, 2, 1)                            # [n, 1, t'', period]
-        fmap.append(y)
-        fmap.cl.append(y8); fmap.den.append(y.numel() // 2)
-        return torch.flatten(y, 1, -1), fmap
-
-
-def _dense_grouped_weight(l, pad_in=0):
-    """Kernel-layout [k][c_out][c_in] operand of a (possibly grouped) Conv1d, block-diagonal, autograd-connected."""
-    w = l.weight                                                          # [c_out][c_in/groups][k]
-    if l.groups > 1:
-        og = w.size(0) // l.groups
-        ig = w.size(1)
-        w = torch.cat([F.pad(w[g * og:(g + 1) * og], (0, 0, g * ig, (l.groups - 1 - g) * ig)) for g in range(l.groups)], 0)
-    if pad_in:
-        w = F.pad(w, (0, 0, 0, pad_in))
-    return w.permute(2, 0, 1).contiguous()
+        """x [n, 1, t] -> (logits [n, t'*p], fmap list in the reference's [n, c, t', period] layout, as views of the
+        channels-last activations).  The (k, 1) convolutions act along t' only: the period axis is folded into the batch
+        and the whole discriminator runs as one autograd node (disc_cl.DiscFn)."""
+        from . import disc_cl
+        (y8, hs), = disc_cl.run([self], x[:, 0, :].float())
+        return _disc_outputs(self.period, x.size(0), y8, hs)
 
 
 class DiscriminatorS(nn.Module):
     # models.py:338-361
+    period = 1
+
     def __init__(self, use_spectral_norm=False):
         super().__init__()
         if use_spectral_norm:
@@ -428,44 +385,17 @@ class DiscriminatorS(nn.Module):
             WNConv1d(1024, 1024, 41, 4, groups=256, padding=20), WNConv1d(1024, 1024, 5, 1, padding=2)])
         self.conv_post = WNConv1d(1024, 1, 3, 1, padding=1)
 
-    # VITS_DISC_S=library selects the MIOpen convolutions (A/B measurements only)
-    use_hip = os.environ.get("VITS_DISC_S", "hip") != "library"
-
     def forward(self, x):
-        return self.forward_hip(x) if DiscriminatorS.use_hip else self.forward_rocm(x)
-
-    def forward_rocm(self, x):
-        fmap = []
-        for i, l in enumerate(self.convs):
-            x = F.leaky_relu(_first_layer_fp32(l, x) if i == 0 else l(x), modules.LRELU_SLOPE)
-            fmap.append(x)
-        x = self.conv_post(x)
-        fmap.append(x)
-        return torch.flatten(x, 1, -1), fmap
+        return self.forward_hip(x)
 
     def forward_hip(self, x):
         """x [n, 1, t] -> (logits [n, t'], fmap list in the reference's [n, c, t'] layout, as views of channels-last
-        activations).  Every layer runs on the flat-row MFMA kernel with leaky-relu fused; the grouped layers
-        (groups 4..256, 4 input channels per group) take DENSE block-diagonal operands from the weight arena and the
-        kernel only walks the input channels a tile of output channels can see (vits_conv_desc.groups)."""
-        from . import wn_cl, weight_arena as WA
-        dtype = wn_cl.compute_dtype()
-        fmap = _Fmaps()
-        h = F.pad(x.transpose(1, 2), (0, 7)).to(dtype)                   # [n, t, 1] -> c_in 8 (vector width), zero weights there
-        for i, l in enumerate(self.convs):
-            groups = l.groups
-            w = WA.handle_for(l)
-            if w is None:                                                # outside an arena scope: torch-prepared operand
-                w, groups = _dense_grouped_weight(l, 7 if i == 0 else 0), 1
-            h = wn_cl.conv_cl(h, w, l.bias, pad=l.padding, stride=l.stride, out_slope=modules.LRELU_SLOPE, dtype=dtype, groups=groups)
-            fmap.append(h.transpose(1, 2))
-            fmap.cl.append(h); fmap.den.append(h.numel() // 2)
-        l = self.conv_post
-        y8 = wn_cl.conv_cl(h, wn_cl.weight_of(l, pad_out=7), wn_cl.bias_of(l, 7), pad=l.padding, dtype=dtype)
-        y = y8[..., :1].transpose(1, 2)                                  # channels 1..7 are exactly zero
-        fmap.append(y)
-        fmap.cl.append(y8); fmap.den.append(y.numel() // 2)
-        return torch.flatten(y, 1, -1), fmap
+        activations).  One autograd node (disc_cl.DiscFn); the grouped layers (groups 4..256, 4 input channels per group)
+        take DENSE block-diagonal operands and the kernel only walks the input channels a tile of output channels can see
+        (vits_conv_desc.groups)."""
+        from . import disc_cl
+        (y8, hs), = disc_cl.run([self], x[:, 0, :].float())
+        return _disc_outputs(1, x.size(0), y8, hs)
 
 
 class MultiPeriodDiscriminator(nn.Module):
@@ -477,36 +407,20 @@ class MultiPeriodDiscriminator(nn.Module):
         discs = discs + [DiscriminatorP(i, use_spectral_norm=use_spectral_norm) for i in periods]
         self.discriminators = nn.ModuleList(discs)
 
-    # measured: 63.9 ms/step with the six discriminators on six streams vs 52.1 ms on one (graph branches cost more in
-    # cross-stream dependencies than the overlap of these small launches returns) — kept as an opt-in experiment
-    parallel_streams = os.environ.get("VITS_D_STREAMS", "0") == "1"
-
     def forward(self, y, y_hat):
-        """Real and generated waveforms go through each discriminator as ONE batch of 2b (the
-        reference runs them as two passes, models.py:375-377; the convolutions have no cross-batch
-        coupling, so the results are identical and every kernel sees twice the rows)."""
-        from . import weight_arena
+        """Real and generated waveforms go through every discriminator as ONE batch of 2b (the reference runs them as two
+        passes, models.py:375-377; the convolutions have no cross-batch coupling, so the results are identical and every
+        kernel sees twice the rows), and all six discriminators are ONE autograd node (disc_cl.DiscFn).  When the
+        discriminator is frozen (generator step) only the generated half needs a backward: n_lo = b."""
+        from . import disc_cl, weight_arena
+        from .reduce import FmapLists
         b = y.size(0)
         yy = torch.cat([y, y_hat], 0)
-        y_d_rs, y_d_gs, fmap_rs, fmap_gs = [], [], [], []
+        frozen = not any(p.requires_grad for p in self.parameters())
         with weight_arena.scope(self, MultiPeriodDiscriminator._arena_specs):
-            if yy.is_cuda and MultiPeriodDiscriminator.parallel_streams:
-                # the six discriminators are independent chains of small launches: each runs on its own stream (forward here,
-                # backward on the same stream by autograd's rule), forking from and joining the caller's stream — parallel
-                # branches of the captured graph
-                cur = torch.cuda.current_stream(yy.device)
-                if getattr(self, "_streams", None) is None:
-                    self._streams = [torch.cuda.Stream(yy.device) for _ in self.discriminators]
-                outs = []
-                for d, s in zip(self.discriminators, self._streams):
-                    s.wait_stream(cur)
-                    with torch.cuda.stream(s):
-                        outs.append(d(yy))
-                for s in self._streams:
-                    cur.wait_stream(s)
-            else:
-                outs = [d(yy) for d in self.discriminators]
-        from .reduce import FmapLists
+            res = disc_cl.run(list(self.discriminators), yy[:, 0, :].float(), n_lo=b if frozen else 0)
+        outs = [_disc_outputs(d.period, 2 * b, y8, hs) for d, (y8, hs) in zip(self.discriminators, res)]
+        y_d_rs, y_d_gs = [], []
         fmap_rs, fmap_gs = FmapLists(), FmapLists()
         cl, den = [], []
         for out, fmap in outs:
@@ -522,16 +436,9 @@ class MultiPeriodDiscriminator(nn.Module):
         from .weight_arena import Spec
         specs = []
         for d in net.discriminators:
-            if isinstance(d, DiscriminatorP) and DiscriminatorP.use_hip:
-                specs.append(Spec(d.convs[0], c_in_p=8))
-                specs += [Spec(l) for l in d.convs[1:]]
-                specs.append(Spec(d.conv_post, c_out_p=8))
-            elif isinstance(d, DiscriminatorS) and DiscriminatorS.use_hip:
-                specs.append(Spec(d.convs[0], c_in_p=8))
-                specs += [Spec(l, groups=l.groups) for l in d.convs[1:]]
-                specs.append(Spec(d.conv_post, c_out_p=8))
-            else:           # library (MIOpen) convolutions: weight-norm + dtype for all layers in the same launch
-                specs += [Spec(l, "torch", torch_layout=True) for l in list(d.convs) + [d.conv_post]]
+            specs.append(Spec(d.convs[0], c_in_p=8))
+            specs += [Spec(l, groups=getattr(l, "groups", 1)) for l in d.convs[1:]]
+            specs.append(Spec(d.conv_post, c_out_p=8))
         return specs
 
 
@@ -592,22 +499,27 @@ class SynthesizerTrn(nn.Module):
             return out
 
         def dds_specs(dds):
-            return [Spec(c) for c in dds.convs_1x1]
+            return [Spec(c, bias=True) for c in dds.convs_1x1]
 
-        specs = [Spec(net.enc_q.pre, c_in_p=(net.enc_q.in_channels + 7) // 8 * 8)] + wn_specs(net.enc_q.enc) + [Spec(net.enc_q.proj)]
+        # (bias=True: convolutions that run as single wn_cl.ConvCLFn nodes — their bias gradients ride in the deferred
+        # weight-gradient launches and must reach the parameters through the arena; the fused WN / decoder nodes flush their own)
+        specs = [Spec(net.enc_q.pre, c_in_p=(net.enc_q.in_channels + 7) // 8 * 8, bias=True)] + wn_specs(net.enc_q.enc) + [Spec(net.enc_q.proj, bias=True)]
         # text encoder: q/k/v/o projections, FFN convolutions, output projection
         for att, ffn in zip(net.enc_p.encoder.attn_layers, net.enc_p.encoder.ffn_layers):
-            specs += [Spec(att.conv_q), Spec(att.conv_k), Spec(att.conv_v), Spec(att.conv_o), Spec(ffn.conv_1), Spec(ffn.conv_2)]
+            specs += [Spec(m, bias=True) for m in (att.conv_q, att.conv_k, att.conv_v, att.conv_o, ffn.conv_1, ffn.conv_2)]
+        specs.append(Spec(net.enc_p.proj, bias=True))
         # stochastic duration predictor: every 192-channel 1x1 convolution; the 29-column spline projections padded to 32
         if isinstance(net.dp, StochasticDurationPredictor):
             dp = net.dp
-            specs += [Spec(dp.pre), Spec(dp.proj), Spec(dp.post_proj), Spec(dp.post_pre, c_in_p=8)] + dds_specs(dp.convs) + dds_specs(dp.post_convs)
+            specs += [Spec(dp.pre, bias=True), Spec(dp.proj, bias=True), Spec(dp.post_proj, bias=True), Spec(dp.post_pre, c_in_p=8, bias=True)]
+            specs += dds_specs(dp.convs) + dds_specs(dp.post_convs)
             for fl in list(dp.flows) + list(dp.post_flows):
                 if isinstance(fl, modules.ConvFlow):
-                    specs += dds_specs(fl.convs) + [Spec(fl.pre, c_in_p=8), Spec(fl.proj, c_out_p=(fl.proj.out_channels + 7) // 8 * 8)]
+                    specs += dds_specs(fl.convs) + [Spec(fl.pre, c_in_p=8, bias=True),
+                                                    Spec(fl.proj, c_out_p=(fl.proj.out_channels + 7) // 8 * 8, bias=True)]
         for fl in net.flow.flows:
             if isinstance(fl, modules.ResidualCouplingLayer):
-                specs += [Spec(fl.pre)] + wn_specs(fl.enc) + [Spec(fl.post)]
+                specs += [Spec(fl.pre, bias=True)] + wn_specs(fl.enc) + [Spec(fl.post, bias=True)]
         dec = net.dec
         specs.append(Spec(dec.conv_pre))
         for i, up in enumerate(dec.ups):

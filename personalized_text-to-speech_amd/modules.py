@@ -166,7 +166,7 @@ class DDSConv(nn.Module):
             sep = self.convs_sep[i]
             y = rowops.dwconv(x, sep.weight, sep.bias, lengths, sep.dilation)
             y = rowops.ln_act(y, self.norms_1[i].gamma, self.norms_1[i].beta, None, self.norms_1[i].eps, 1)
-            y = wn_cl.conv_cl(y, wn_cl.weight_of(self.convs_1x1[i]), self.convs_1x1[i].bias, dtype=x.dtype)
+            y = wn_cl.conv_cl(y, wn_cl.weight_of(self.convs_1x1[i]), wn_cl.bias_of(self.convs_1x1[i]), dtype=x.dtype)
             if drop:
                 y = rowops.ln_act(y, self.norms_2[i].gamma, self.norms_2[i].beta, None, self.norms_2[i].eps, 1)
                 x = x + self.drop(y)
@@ -326,9 +326,9 @@ class ResidualCouplingLayer(nn.Module):
             lengths = mask_cl[:, :, 0].sum(-1).to(torch.int32)
         half = self.half_channels
         x0, x1 = x[..., :half], x[..., half:]
-        h = wn_cl.conv_cl(x0, wn_cl.weight_of(self.pre), self.pre.bias, lengths, mask_out=True)
+        h = wn_cl.conv_cl(x0, wn_cl.weight_of(self.pre), wn_cl.bias_of(self.pre), lengths, mask_out=True)
         h = wn_cl.wn_forward_cl(self.enc, h, lengths, g)
-        stats = wn_cl.conv_cl(h, wn_cl.weight_of(self.post), self.post.bias, lengths, mask_out=True).to(x.dtype)
+        stats = wn_cl.conv_cl(h, wn_cl.weight_of(self.post), wn_cl.bias_of(self.post), lengths, mask_out=True).to(x.dtype)
         if not self.mean_only:
             m, logs = stats[..., :half], stats[..., half:]
         else:
@@ -372,7 +372,7 @@ class ConvFlow(nn.Module):
         x0, x1 = x[..., :1], x[..., 1:]
         # Conv1d(1, C, 1): the single input channel is padded to the 8-wide vector (zero weights there) so that the layer and
         # both of its gradients run on the matrix-core kernels (the broadcast form costs two full-tensor torch reductions)
-        h = wn_cl.conv_cl(F.pad(x0, (0, 7)).to(dtype), wn_cl.weight_of(self.pre, pad_in=7), self.pre.bias, dtype=dtype)
+        h = wn_cl.conv_cl(F.pad(x0, (0, 7)).to(dtype), wn_cl.weight_of(self.pre, pad_in=7), wn_cl.bias_of(self.pre), dtype=dtype)
         h = self.convs.forward_cl(h, lengths, mask_cl, g)
         n_par = self.num_bins * 3 - 1
         pad = (-n_par) % 8                                                                   # 29 -> 32 output columns

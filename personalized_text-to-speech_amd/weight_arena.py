@@ -22,11 +22,18 @@ from . import _lib
 _DT = {torch.float32: 0, torch.bfloat16: 2}
 _current = None            # dict (id(module), part) -> handle tensor, valid inside a scope
 _registry = {}             # handle.data_ptr() -> (arena, index)
+_bias_registry = {}        # bias handle.data_ptr() -> (arena, bias index)
 
 
 class Spec:
-    def __init__(self, module, part=None, row_lo=0, n_rows=None, c_out_p=None, c_in_p=None, transpose=False, torch_layout=False, groups=1):
+    def __init__(self, module, part=None, row_lo=0, n_rows=None, c_out_p=None, c_in_p=None, transpose=False, torch_layout=False, groups=1,
+                 bias=False):
+        """bias=True: the module's bias is managed by the arena too (padded to c_out_p, fp32): wn_cl.bias_of() then hands the layer
+        node an arena bias handle, and the bias gradient reaches the parameter through PrepFn.backward — i.e. AFTER the deferred
+        second stages of the weight-gradient launches (which also produce the bias gradients) have run."""
         self.module, self.part, self.transpose, self.torch_layout, self.groups = module, part, transpose, torch_layout, groups
+        self.bias = module.bias if (bias and getattr(module, "bias", None) is not None) else None
+        assert self.bias is None or (row_lo == 0 and n_rows is None and not transpose)
         has_g = hasattr(module, "weight_g")
         self.v = module.weight_v if has_g else module.weight
         self.g = module.weight_g if has_g else None
@@ -107,7 +114,21 @@ class WeightArena:
         self.handles = [cview(self.handle, o, s) if s.groups > 1 else view(self.w_fwd if s.torch_layout else self.handle, o, s, s.fwd_shape)
                         for o, s in zip(offs, specs)]
         self.dws = [cview(self.dw, o, s) if s.groups > 1 else view(self.dw, o, s, s.fwd_shape) for o, s in zip(offs, specs)]
-        self.ptrs = [p.data_ptr() for p in self.params]
+        # arena-managed biases: fp32, padded to c_out_p, one flat buffer + one flat gradient buffer
+        self.bias_specs = [i for i, s in enumerate(specs) if s.bias is not None]
+        self.bias_params = [specs[i].bias for i in self.bias_specs]
+        self.b_off, boff = [], 0
+        for i in self.bias_specs:
+            self.b_off.append(boff)
+            boff += (specs[i].c_out_p + 7) & ~7
+        self.b_flat = torch.zeros(max(boff, 8), dtype=torch.float32, device=dev)
+        self.db_flat = torch.zeros(max(boff, 8), dtype=torch.float32, device=dev)
+        self.bias_handles = [self.b_flat[o:o + specs[i].c_out_p] for o, i in zip(self.b_off, self.bias_specs)]
+        self.bias_live = [self.b_flat[o:o + specs[i].c_out] for o, i in zip(self.b_off, self.bias_specs)]
+        self.db_views = [self.db_flat[o:o + specs[i].c_out_p] for o, i in zip(self.b_off, self.bias_specs)]
+        for j, h in enumerate(self.bias_handles):
+            _bias_registry[h.data_ptr()] = (self, j)
+        self.ptrs = [p.data_ptr() for p in self.params + self.bias_params]
         # Every forward overwrites the shared operand / gradient buffers.  `gen` counts forwards, `claimed` the weight-gradient
         # slots written since the last forward: PrepFn.backward refuses to hand out gradients computed from operands a later
         # forward has overwritten, and a slot written twice in one backward (a module used twice in one graph) is refused too.
@@ -125,12 +146,14 @@ class WeightArena:
 
     def stale(self):
         """Parameters re-allocated (e.g. .to(device)) or replaced (remove_weight_norm folds weight_g / weight_v into `weight`)."""
-        if any(p.data_ptr() != q for p, q in zip(self.params, self.ptrs)):
+        if any(p.data_ptr() != q for p, q in zip(self.params + self.bias_params, self.ptrs)):
             return True
         return any((s.g is not None) != ("weight_g" in s.module._parameters) for s in self.specs)
 
     def prepare(self):
-        return PrepFn.apply(self, *self.params)
+        """-> (weight handles, bias handles)"""
+        out = PrepFn.apply(self, *self.params, *self.bias_params)
+        return out[:self.n], out[self.n:]
 
 
 class PrepFn(torch.autograd.Function):
@@ -148,12 +171,15 @@ class PrepFn(torch.autograd.Function):
             rc = _lib.lib().vits_weight_prep_transpose(arena.tiles.data_ptr(), arena.n_tiles, arena.table.data_ptr(), _DT[arena.dtype],
                                                        arena.w_fwd.data_ptr(), arena.w_bwd.data_ptr(), _lib.stream_ptr())
             _lib.check(rc, "vits_weight_prep_transpose")
+        if arena.bias_params:
+            torch._foreach_copy_(arena.bias_live, [b.detach() for b in arena.bias_params])
         ctx.arena = arena
-        return tuple(h.detach() for h in arena.handles)
+        return tuple(h.detach() for h in arena.handles) + tuple(h.detach() for h in arena.bias_handles)
 
     @staticmethod
-    def backward(ctx, *dws):
+    def backward(ctx, *grads):
         arena = ctx.arena
+        dws, dbs = grads[:arena.n], grads[arena.n:]
         if ctx.gen != arena.gen:
             raise RuntimeError(
                 "weight_arena: this backward belongs to forward #%d, but forward #%d has since overwritten the arena's shared "
@@ -164,10 +190,16 @@ class PrepFn(torch.autograd.Function):
         arena.claimed.clear()
         # gradient accumulation (no zero_grad between two backwards): a param.grad that still aliases `dparam` would be
         # overwritten below and then added to itself by autograd — detach it into its own storage first
-        base = arena.dparam.untyped_storage().data_ptr()
-        for p in arena.params:
-            if p.grad is not None and p.grad.untyped_storage().data_ptr() == base:
-                p.grad = p.grad.clone()
+        for params, buf in ((arena.params, arena.dparam), (arena.bias_params, arena.db_flat)):
+            base = buf.untyped_storage().data_ptr()
+            for p in params:
+                if p.grad is not None and p.grad.untyped_storage().data_ptr() == base:
+                    p.grad = p.grad.clone()
+        for j, d in enumerate(dbs):
+            if d is None:
+                arena.db_views[j].zero_()
+            elif d.data_ptr() != arena.db_views[j].data_ptr():
+                arena.db_views[j].copy_(d.reshape(arena.db_views[j].shape))
         for i, d in enumerate(dws):
             if d is None:
                 arena.dws[i].zero_()
@@ -178,7 +210,8 @@ class PrepFn(torch.autograd.Function):
         _lib.check(rc, "vits_weight_prep_bwd")
         # FRESH views: autograd's AccumulateGrad installs an incoming gradient as param.grad without a copy only when
         # nobody else references the tensor object; handing out the cached views costs one copy kernel per parameter
-        return (None, *[arena.dparam[o:o + p.numel()].view_as(p) for o, p in zip(arena.p_off, arena.params)])
+        return (None, *[arena.dparam[o:o + p.numel()].view_as(p) for o, p in zip(arena.p_off, arena.params)],
+                *[arena.db_flat[o:o + p.numel()].view_as(p) for o, p in zip(arena.b_off, arena.bias_params)])
 
 
 class Resolved:
@@ -238,6 +271,18 @@ def handle_for(module, part=None):
     return _current.get((id(module), part))
 
 
+def bias_handle_for(module):
+    """Inside a scope: the arena-managed (padded, fp32) bias of `module`, if its Spec asked for one; else None."""
+    if _current is None:
+        return None
+    return _current.get((id(module), "__bias__"))
+
+
+def bias_slot(bias):
+    """(arena, index) if `bias` is an arena bias handle, else None."""
+    return _bias_registry.get(bias.data_ptr()) if bias is not None else None
+
+
 class scope:
     """Prepare all registered convolutions of `root` for the duration of a forward pass."""
 
@@ -252,9 +297,11 @@ class scope:
         if arena is None or arena.stale():
             arena = WeightArena(self.collect(self.root), dtype)
             cache[dtype] = arena
-        handles = arena.prepare()
+        handles, bias_handles = arena.prepare()
         self.prev = _current
         _current = {(id(s.module), s.part): h for s, h in zip(arena.specs, handles)}
+        for i, h in zip(arena.bias_specs, bias_handles):
+            _current[(id(arena.specs[i].module), "__bias__")] = h
         return arena
 
     def __exit__(self, *exc):

@@ -53,6 +53,7 @@ class ConvCLFn(torch.autograd.Function):
         y = K.conv1d_cl_raw(xd, R.fwd, None if bias is None else bias.detach().float(), res=rd, lengths=lengths, dil=dil, pad=pad,
                             stride=stride, in_slope=in_slope, flags=flags, out_slope=out_slope, groups=groups)
         ctx.groups = groups
+        ctx.bias_slot = WA.bias_slot(bias)
         ctx.save_for_backward(xd, y if out_slope is not None else xd)
         ctx.R, ctx.out_slope = R, out_slope
         ctx.lengths, ctx.cfg, ctx.has_bias, ctx.x_dtype = lengths, (dil, pad, in_slope, mask_in, mask_out, stride), bias is not None, x.dtype
@@ -73,11 +74,19 @@ class ConvCLFn(torch.autograd.Function):
         dw = db = None
         want_db = ctx.has_bias and ctx.needs_input_grad[3]
         if ctx.needs_input_grad[2]:
+            dw_out = R.claim_dw()
+            deferred = dw_out is not None and R.defer is not None
             if want_db and dy.size(2) % 8 == 0:
-                db = torch.empty(dy.size(2), dtype=torch.float32, device=dy.device)
+                # riding in the weight-gradient launch.  When that launch's second stage is deferred (arena), the result is only
+                # final after the arena's flush: then it must live in the arena's own bias-gradient buffer, which reaches the
+                # parameter through PrepFn.backward — a fresh tensor handed to autograd now could be read before it is written
+                if ctx.bias_slot is not None:
+                    db = ctx.bias_slot[0].db_views[ctx.bias_slot[1]]
+                elif not deferred:
+                    db = torch.empty(dy.size(2), dtype=torch.float32, device=dy.device)
             dw = K.conv1d_cl_wgrad_raw(xd, dy, k, lengths=ctx.lengths, dil=dil, pad=pad, stride=stride, in_slope=in_slope,
-                                       flags=K.CONV_MASK_IN if mask_in else 0, out=R.claim_dw(), dbias=db, groups=ctx.groups,
-                                       defer=R.defer if R.dw is not None else None)
+                                       flags=K.CONV_MASK_IN if mask_in else 0, out=dw_out, dbias=db, groups=ctx.groups,
+                                       defer=R.defer if deferred else None)
         if want_db and db is None:
             db = K.colsum(dy)
         dx = None
@@ -113,6 +122,12 @@ def weight_of(module, part=None, pad_in=0, pad_out=0):
 
 
 def bias_of(module, pad_out=0):
+    """The bias operand of a conv module: the arena's padded fp32 bias handle inside a weight_arena.scope whose Spec manages it,
+    else the parameter itself (zero-padded by `pad_out` output channels)."""
+    h = WA.bias_handle_for(module)
+    if h is not None:
+        assert h.numel() == module.bias.numel() + pad_out
+        return h
     b = module.bias
     return torch.nn.functional.pad(b, (0, pad_out)) if (pad_out and b is not None) else b
 

@@ -15,6 +15,7 @@ def emulated(pkg, monkeypatch):
     monkeypatch.setattr(pkg.kernels, "colsum", cl_emul.colsum)
     monkeypatch.setattr(pkg.kernels, "conv1d_cl_wgrad_raw", cl_emul.conv1d_cl_wgrad_raw)
     cl_emul.install_arena_emulation(monkeypatch)
+    cl_emul.install_disc(monkeypatch)
     return pkg
 
 
@@ -39,13 +40,10 @@ def test_discriminator_p(emulated, period):
         assert rel_err(p.grad, sd["d." + k].grad) < 5e-5, k
 
 
-@pytest.mark.parametrize("hip_p", [False, True])
-def test_mpd_through_arena(emulated, monkeypatch, hip_p):
-    """MultiPeriodDiscriminator with the weight-norm of all 37 layers coming from the arena — period discriminators on
-    the channels-last kernels (hip_p) or everything on library convolutions with torch-layout operands: outputs and
-    parameter gradients equal the oracle."""
+def test_mpd_through_arena(emulated, monkeypatch):
+    """MultiPeriodDiscriminator as one autograd node (disc_cl.DiscFn) with the weight-norm of all 37 layers coming from the
+    arena: outputs and parameter gradients equal the oracle."""
     pkg = emulated
-    monkeypatch.setattr(pkg.models.DiscriminatorP, "use_hip", hip_p)
     torch.manual_seed(0)
     d = pkg.MultiPeriodDiscriminator(False)
     sd = {k: v.detach().clone().requires_grad_(True) for k, v in d.state_dict().items()}
@@ -85,3 +83,22 @@ def test_discriminator_s_channels_last(emulated, in_scope):
     (lo.pow(2).mean() + sum(f.abs().mean() for f in fo)).backward()
     for k, p in d.named_parameters():
         assert rel_err(p.grad, sd["d." + k].grad) < 5e-5, k
+
+
+def test_mpd_generator_step_half_batch(emulated):
+    """Frozen discriminator (the generator step): only the generated half of the batch runs backward (n_lo = b); the gradient
+    wrt y_hat equals the oracle's, the real half contributes nothing (reference losses.py:11 detaches it)."""
+    pkg = emulated
+    torch.manual_seed(1)
+    d = pkg.MultiPeriodDiscriminator(False)
+    sd = {k: v.detach().clone() for k, v in d.state_dict().items()}
+    for p in d.parameters():
+        p.requires_grad_(False)
+    y = torch.rand(2, 1, 700) * 2 - 1
+    ya, yb = (torch.rand(2, 1, 700) * 2 - 1).requires_grad_(True), None
+    yb = ya.detach().clone().requires_grad_(True)
+    rs, gs, fr, fg = d(y, ya)
+    (pkg.losses.generator_loss(gs)[0] + sum((a.detach() - b).abs().mean() for x, z in zip(fr, fg) for a, b in zip(x, z))).backward()
+    ro, go, fro, fgo = O.mpd(sd, y, yb)
+    (O.generator_loss(go) + sum((a.detach() - b).abs().mean() for x, z in zip(fro, fgo) for a, b in zip(x, z))).backward()
+    assert rel_err(ya.grad, yb.grad) < 2e-5

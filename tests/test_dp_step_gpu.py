@@ -43,7 +43,8 @@ def _run_children(tmp_path, mode):
                 q.kill()
             pytest.fail("data-parallel child ranks timed out")
         logs.append(o)
-    assert all(p.returncode == 0 for p in procs), "\n".join(l[-3000:] for l in logs)
+    keep = lambda l: "\n".join(x for x in l.splitlines() if "Warning" not in x and "warn" not in x and "run_backward" not in x)[-6000:]
+    assert all(p.returncode == 0 for p in procs), f"exit codes {[p.returncode for p in procs]}\n" + "\n-----\n".join(keep(l) for l in logs)
     return [np.load(o) for o in outs]
 
 

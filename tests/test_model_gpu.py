@@ -165,3 +165,64 @@ def test_text_embedding_gradient_matches_torch(pkg):
     (ga,) = torch.autograd.grad(a, w, g)
     (gb,) = torch.autograd.grad(b, w, g)
     assert float((ga - gb).abs().max() / gb.abs().max()) < 1e-5
+
+
+def test_scale_discriminator_and_edge_layers(pkg):
+    """DiscriminatorS through disc_cl.DiscFn (first-layer / conv_post bandwidth kernels, grouped layers) against the oracle
+    on the CPU: logits, feature maps, input and parameter gradients."""
+    from oracle import vits_torch as O
+    torch.manual_seed(5)
+    d = pkg.models.DiscriminatorS().cuda()
+    sd = {"d." + k: v.detach().cpu().clone().requires_grad_(True) for k, v in d.state_dict().items()}
+    x = (torch.rand(3, 1, 3000) * 2 - 1)
+    xa, xb = x.cuda().requires_grad_(True), x.clone().requires_grad_(True)
+    la, fa = d.forward_hip(xa)
+    lb, fb = O.disc_s(sd, "d", xb)
+    assert rel_err(la, lb) < 1e-4
+    for a, b in zip(fa, fb):
+        assert a.shape == b.shape and rel_err(a, b) < 1e-4
+    (la.pow(2).sum() + sum(f.abs().mean() for f in fa)).backward()
+    (lb.pow(2).sum() + sum(f.abs().mean() for f in fb)).backward()
+    assert rel_err(xa.grad, xb.grad) < 1e-3
+    for k, p in d.named_parameters():
+        assert rel_err(p.grad, sd["d." + k].grad) < 1e-3, k
+
+
+@pytest.mark.parametrize("period", [2, 7, 11])
+def test_period_discriminator_odd_lengths(pkg, period):
+    """Reflect pad folded into the first-layer kernels: lengths that are not a multiple of the period (8192 is not one of
+    3, 5, 7, 11), forward and the gradient wrt the waveform."""
+    from oracle import vits_torch as O
+    torch.manual_seed(period)
+    d = pkg.models.DiscriminatorP(period).cuda()
+    sd = {"d." + k: v.detach().cpu().clone().requires_grad_(True) for k, v in d.state_dict().items()}
+    x = (torch.rand(2, 1, 8192) * 2 - 1)
+    xa, xb = x.cuda().requires_grad_(True), x.clone().requires_grad_(True)
+    la, fa = d.forward_hip(xa)
+    lb, fb = O.disc_p(sd, "d", xb, period)
+    assert la.shape == lb.shape and rel_err(la, lb) < 1e-4
+    for a, b in zip(fa, fb):
+        assert a.shape == b.shape and rel_err(a, b) < 1e-4
+    (la.pow(2).sum() + sum(f.abs().mean() for f in fa)).backward()
+    (lb.pow(2).sum() + sum(f.abs().mean() for f in fb)).backward()
+    assert rel_err(xa.grad, xb.grad) < 1e-3
+    for k, p in d.named_parameters():
+        assert rel_err(p.grad, sd["d." + k].grad) < 1e-3, k
+
+
+def test_mpd_generator_step_half_batch(pkg):
+    """Frozen discriminators (the generator step): backward on the generated half only; d/d y_hat equals the oracle's."""
+    from oracle import vits_torch as O
+    torch.manual_seed(1)
+    d = pkg.MultiPeriodDiscriminator(False).cuda()
+    sd = {k: v.detach().cpu().clone() for k, v in d.state_dict().items()}
+    for p in d.parameters():
+        p.requires_grad_(False)
+    y = torch.rand(2, 1, 2048) * 2 - 1
+    yh = torch.rand(2, 1, 2048) * 2 - 1
+    ya, yb = yh.cuda().requires_grad_(True), yh.clone().requires_grad_(True)
+    rs, gs, fr, fg = d(y.cuda(), ya)
+    (pkg.losses.generator_loss(gs)[0] + pkg.losses.feature_loss(fr, fg)).backward()
+    ro, go, fro, fgo = O.mpd(sd, y, yb)
+    (O.generator_loss(go) + O.feature_loss(fro, fgo)).backward()
+    assert rel_err(ya.grad, yb.grad) < 1e-3
