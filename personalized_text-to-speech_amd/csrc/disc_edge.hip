@@ -78,7 +78,7 @@ __global__ __launch_bounds__(kThreads) void first_fwd(const float* __restrict__ 
 
 // first layer, weight + bias gradient, stage 1: lane = (channel, row chunk); a chunk is RC consecutive output rows of one item.
 // partial[block][(K+1)*c_out]: [tap][co] then the bias sums.
-constexpr int RC = 64;
+constexpr int RC = 16;
 template <typename T, int KMAX>
 __global__ __launch_bounds__(kThreads) void first_wgrad(const float* __restrict__ x, const T* __restrict__ dy, float* __restrict__ partial,
                                                         FirstGeom g, int j_lo) {
@@ -98,6 +98,7 @@ __global__ __launch_bounds__(kThreads) void first_wgrad(const float* __restrict_
     const int r_hi = r_lo + RC < g.R1 ? r_lo + RC : g.R1;
     const int ni = j / g.p, wcol = j - ni * g.p;
     const T* d = dy + ((size_t)j * g.R1) * g.c_out + co;
+#pragma unroll 4
     for (int r1 = r_lo; r1 < r_hi; ++r1) {
       const float dv = to_f(d[(size_t)r1 * g.c_out]);
       acc[KMAX] += dv;
@@ -125,16 +126,33 @@ __global__ __launch_bounds__(kThreads) void first_wgrad(const float* __restrict_
 
 // stage 2 of every reduction in this file: out[map(i)] (+)= sum_b partial[b][i], fixed order.
 // map(i) = (i / n_in) * s_out + (i % n_in) * s_in for i < n_main; the following n_tail elements go to `tail` densely.
-__global__ void reduce_final(const float* __restrict__ partial, int blocks, int n_main, int n_tail, int n_in, long s_in, long s_out,
-                             float* __restrict__ out, float* __restrict__ tail, int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// Workgroup = 32 outputs x 8 slices of the block range (slice g sums blocks g, g+8, ...; the 8 slice sums are then added in
+// slice order): 8x the parallelism of one thread per output, same result for every launch.
+__global__ __launch_bounds__(256) void reduce_final(const float* __restrict__ partial, int blocks, int n_main, int n_tail, int n_in,
+                                                    long s_in, long s_out, float* __restrict__ out, float* __restrict__ tail, int accumulate) {
+  __shared__ float red[8][32];
+  const int ii = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + ii;
   const int n = n_main + n_tail;
-  if (i >= n) return;
   float s = 0.f;
-  for (int b = 0; b < blocks; ++b) s += partial[(size_t)b * n + i];
+  if (i < n) {
+    int b = g;
+    for (; b + 24 < blocks; b += 32) {                        // 4 independent loads in flight
+      const float v0 = partial[(size_t)b * n + i], v1 = partial[(size_t)(b + 8) * n + i];
+      const float v2 = partial[(size_t)(b + 16) * n + i], v3 = partial[(size_t)(b + 24) * n + i];
+      s += v0; s += v1; s += v2; s += v3;
+    }
+    for (; b < blocks; b += 8) s += partial[(size_t)b * n + i];
+  }
+  red[g][ii] = s;
+  __syncthreads();
+  if (g != 0 || i >= n) return;
+  float t = red[0][ii];
+#pragma unroll
+  for (int q = 1; q < 8; ++q) t += red[q][ii];
   float* dst = i < n_main ? out + (long)(i / n_in) * s_out + (long)(i % n_in) * s_in : (tail ? tail + (i - n_main) : nullptr);
   if (!dst) return;
-  *dst = accumulate ? *dst + s : s;
+  *dst = accumulate ? *dst + t : t;
 }
 
 // first layer, data gradient wrt the waveform (generator step): thread = one sample of one item in [n_lo, n)
@@ -380,7 +398,7 @@ int vits_disc_first_wgrad(int dtype, const float* x, const void* dy, float* dw, 
   else
     return VITS_E_UNSUPPORTED;
   const int n_main = k * c_out, n_tail = c_out;
-  hipLaunchKernelGGL(reduce_final, dim3((n_main + n_tail + 255) / 256), dim3(256), 0, s, ws, (int)blocks, n_main, n_tail, n_main, 8L, 0L,
+  hipLaunchKernelGGL(reduce_final, dim3((n_main + n_tail + 31) / 32), dim3(256), 0, s, ws, (int)blocks, n_main, n_tail, n_main, 8L, 0L,
                      dw, dbias, accumulate);
   return vits::check_launch("vits_disc_first_wgrad");
 }
@@ -459,7 +477,7 @@ int vits_disc_post_wgrad(int dtype, const void* dy8, const void* h, float* dw, f
   else
     hipLaunchKernelGGL((post_wgrad<float, 4>), dim3(blocks), dim3(128), 0, s, static_cast<const float*>(dy8), static_cast<const float*>(h), ws, J, R, c_in, k, pad, 0);
   const int n_main = k * c_in;
-  hipLaunchKernelGGL(reduce_final, dim3((n_main + 1 + 255) / 256), dim3(256), 0, s, ws, (int)blocks, n_main, 1, c_in, 1L, 8L * c_in, dw, dbias, accumulate);
+  hipLaunchKernelGGL(reduce_final, dim3((n_main + 1 + 31) / 32), dim3(256), 0, s, ws, (int)blocks, n_main, 1, c_in, 1L, 8L * c_in, dw, dbias, accumulate);
   return vits::check_launch("vits_disc_post_wgrad");
 }
 

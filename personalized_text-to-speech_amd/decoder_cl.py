@@ -173,7 +173,7 @@ class DecoderFn(torch.autograd.Function):
             if bias_slot is not None:
                 db = torch.empty(dy.size(2), dtype=torch.float32, device=dy.device)
                 grads[bias_slot] = db
-            return WG(x, dy, k, out=R[slot].claim_dw(), dbias=db, defer=defer, **kw)
+            return WG(x, dy, k, out=R[slot].claim_dw(ctx), dbias=db, defer=defer, **kw)
 
         def bias_grad(d):
             return K.colsum(d if d.is_contiguous() else d.contiguous())

@@ -212,7 +212,7 @@ class DiscFn(torch.autograd.Function):
             if dy8 is not None:
                 dy8 = cont(dy8.to(dtype))
                 if need_w:
-                    dw = _dw_buffer(R[ip], (pk, 8, hL.size(2)), xd.device)
+                    dw = _dw_buffer(R[ip], (pk, 8, hL.size(2)), xd.device, ctx)
                     grads[ip + 1] = post_wgrad(dy8, hL, dw, pk, ppad)
                     grads[ip] = dw
                 dcur = post_dgrad(dy8, R[ip].fwd, cont(dhs[-1]), hL, lo, pk, ppad)
@@ -231,7 +231,7 @@ class DiscFn(torch.autograd.Function):
                     continue
                 if need_w:
                     db = torch.empty(co, device=xd.device, dtype=torch.float32)
-                    grads[iw] = WG(x_in, dcur, kk, pad=pd, stride=st, out=R[iw].claim_dw(), dbias=db, groups=g, defer=defer)
+                    grads[iw] = WG(x_in, dcur, kk, pad=pd, stride=st, out=R[iw].claim_dw(ctx), dbias=db, groups=g, defer=defer)
                     grads[iw + 1] = db
                 dcur = C(dcur, WA.bwd_operand(R[iw]), None, res=None if dprev is None else cont(dprev[lo:]), mg_src=x_in, mg_slope=SLOPE,
                          pad=(kk - 1) - pd, in_div=st, t_out=x_in.size(1) if st != 1 else None, groups=g)
@@ -239,7 +239,7 @@ class DiscFn(torch.autograd.Function):
             if dcur is not None:
                 k, s1, pad, c1 = plan.first
                 if need_w:
-                    dw = _dw_buffer(R[base], (k, c1, 8), xd.device)
+                    dw = _dw_buffer(R[base], (k, c1, 8), xd.device, ctx)
                     grads[base + 1] = first_wgrad(xd, dcur, dw, p, k, s1, pad, c1)
                     grads[base] = dw
                 if need_x:
@@ -258,10 +258,10 @@ def _f32(b):
     return None if b is None else b.detach().float()
 
 
-def _dw_buffer(res, shape, device):
+def _dw_buffer(res, shape, device, owner=None):
     """The arena's gradient view of an edge layer (its padding channels stay zero: the edge kernels never write them), or a
     zeroed tensor outside an arena."""
-    dw = res.claim_dw()
+    dw = res.claim_dw(owner)
     if dw is None:
         dw = torch.zeros(shape, device=device, dtype=torch.float32)
     assert tuple(dw.shape) == tuple(shape)

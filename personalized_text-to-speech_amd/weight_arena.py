@@ -132,7 +132,7 @@ class WeightArena:
         # Every forward overwrites the shared operand / gradient buffers.  `gen` counts forwards, `claimed` the weight-gradient
         # slots written since the last forward: PrepFn.backward refuses to hand out gradients computed from operands a later
         # forward has overwritten, and a slot written twice in one backward (a module used twice in one graph) is refused too.
-        self.gen, self.claimed = 0, set()
+        self.gen, self.claimed = 0, {}
         for i, h in enumerate(self.handles):
             _registry[h.data_ptr()] = (self, i)
 
@@ -222,15 +222,17 @@ class Resolved:
     def __init__(self, fwd, bwd, dw, defer=None, arena=None, index=-1):
         self.fwd, self.bwd, self.dw, self.defer, self.arena, self.index = fwd, bwd, dw, defer, arena, index
 
-    def claim_dw(self):
-        """The arena's weight-gradient view for this convolution (None outside an arena), claimed for the current backward:
-        a second claim before the arena's own backward means the same weight is used twice in one graph, and autograd would
-        sum the one shared view with itself."""
+    def claim_dw(self, owner=None):
+        """The arena's weight-gradient view for this convolution (None outside an arena), claimed by the autograd node `owner`
+        for the current backward: a claim by a DIFFERENT node before the arena's own backward has run means the same weight
+        is used twice in one graph, and autograd would sum the one shared view with itself.  (The same node claiming again is
+        a repeated backward over a retained graph: fine, it rewrites the same values.)"""
         if self.arena is not None:
-            if self.index in self.arena.claimed:
+            prev = self.arena.claimed.get(self.index)
+            if prev is not None and prev != id(owner):
                 raise RuntimeError("weight_arena: a convolution weight is used twice in one autograd graph; the arena keeps one "
                                    "gradient buffer per weight (call the module once per forward, or outside weight_arena.scope)")
-            self.arena.claimed.add(self.index)
+            self.arena.claimed[self.index] = id(owner)
         return self.dw
 
 

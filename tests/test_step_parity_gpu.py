@@ -89,12 +89,17 @@ def test_step_matches_reference_fp32(pkg):
             assert float((new - ref).norm() / ref.norm()) < TOL, k
             du, dr = new - old[name].double().cpu(), ref - old[name].double().cpu()
             assert float(dr.norm()) > 0 and float((du * dr).sum() / (du.norm() * dr.norm())) > 0.99, k
-    for names, params, ref in ((names_g, pg, g["new_g_sum"]), (names_d, pd, g["new_d_sum"])):
+    for names, params, ref, gn in ((names_g, pg, g["new_g_sum"], g["gradnorm_g"]), (names_d, pd, g["new_d_sum"], g["gradnorm_d"])):
         got = np.array([float(params[k].detach().double().sum()) for k in names])
         numel = np.array([params[k].numel() for k in names])
-        # a parameter's sum moves by at most lr * numel in one AdamW step; agree to a small fraction of that
-        assert np.all(np.abs(got - ref) <= 0.05 * cfg["train"]["learning_rate"] * numel + 1e-4 * np.abs(ref)), \
-            [(k, a, b) for k, a, b, n in zip(names, got, ref, numel) if abs(a - b) > 0.05 * cfg["train"]["learning_rate"] * n + 1e-4 * abs(b)][:5]
+        # a parameter's sum moves by at most lr * numel in one AdamW step; agree to a small fraction of that.  Parameters whose
+        # true gradient is zero (the key bias of an attention layer: softmax is invariant to it) get lr * sign(rounding noise)
+        # from AdamW's first step and are skipped.
+        live = gn > 1e-5 * gn.max()
+        bad = [(k, a, b) for k, a, b, n, ok in zip(names, got, ref, numel, live)
+               if ok and abs(a - b) > 0.05 * cfg["train"]["learning_rate"] * n + 1e-4 * abs(b)]
+        assert not bad, bad[:5]
+        assert live.sum() > 0.9 * len(names)
 
 
 def test_step_bf16_close_to_reference(pkg):

@@ -18,7 +18,7 @@ def test_prep_forward_and_backward(pkg, dtype, tol):
     torch.manual_seed(3)
     net = pkg.SynthesizerTrn(hps.n_symbols, 513, 32, n_speakers=4, **hps.model).cuda()
     arena = WA.WeightArena(pkg.SynthesizerTrn._arena_specs(net), dtype)
-    handles = arena.prepare()
+    handles, bias_handles = arena.prepare()
     torch.cuda.synchronize()
     got_f, got_b = arena.w_fwd.clone(), arena.w_bwd.clone()
     cl_emul.weight_prep(arena)
