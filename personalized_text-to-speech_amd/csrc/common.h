@@ -21,5 +21,13 @@ __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; 
 
 // csrc/conv1d_flat.hip: flat-row (gathering) variant of the channels-last convolution
 int conv1d_flat_dispatch(const vits_conv_desc& d, int t_out, hipStream_t s);
+// csrc/conv1d_ring.hip: LDS-DMA ring variant (bf16, c_in % 64 == 0, k >= 2); VITS_E_UNSUPPORTED = take another kernel
+int conv1d_ring_dispatch(const vits_conv_desc& d, int t_out, hipStream_t s);
+
+// Raise a kernel's dynamic-LDS limit to the hardware maximum (a per-device function attribute): once per device and
+// kernel, to a FIXED value — a per-launch value would be whatever the LAST call set by the time a captured graph replays.
+inline hipError_t ensure_max_dynamic_lds(const void* kern, int reserve_static = 0) {
+  return hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesMax - reserve_static);
+}
 
 }  // namespace vits

@@ -463,6 +463,13 @@ extern "C" int vits_conv1d_cl(const vits_conv_desc* desc, void* stream) {
   const bool must_flat = in_div > 1 || (d.flags & VITS_CONV_FLAT) != 0 || d.groups > 1;
   if (must_flat && !flat_ok) return VITS_E_UNSUPPORTED;
   static const bool auto_flat = !(getenv("VITS_FLAT_AUTO") && getenv("VITS_FLAT_AUTO")[0] == '0');
+  // deep-prefetch ring kernel (csrc/conv1d_ring.hip) for layers with >= 128 input channels and k >= 2: measured faster than or
+  // equal to the one-stage-ahead kernels on every such shape of the step (tools/ubench_conv.py; 2.3x on the 1024-channel layers)
+  static const int ring_mode = getenv("VITS_RING") ? atoi(getenv("VITS_RING")) : 1;             // 0 = off (A/B measurements)
+  if (ring_mode && d.dtype == VITS_DT_BF16 && flat_ok && in_div == 1 && d.groups <= 1 && d.k >= 2 && d.c_in >= 128 && d.c_out >= 96) {
+    const int rc = vits::conv1d_ring_dispatch(d, t_out, s);
+    if (rc != VITS_E_UNSUPPORTED) return rc;
+  }
   if (must_flat || (flat_ok && (d.stride > 1 || (auto_flat && t_out <= 80 && d.b >= 8)))) {
     const int rc = vits::conv1d_flat_dispatch(d, t_out, s);
     if (rc != VITS_E_UNSUPPORTED || must_flat) return rc;

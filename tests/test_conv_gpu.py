@@ -289,3 +289,41 @@ def test_wgrad_fused_reduction_is_bitwise_the_two_launch_result(pkg):
                 assert all(torch.equal(u, v) for u, v in zip(res[fused], (dw, db, acc, dba)))
             res[fused] = (dw, db, acc, dba)
         assert all(torch.equal(u, v) for u, v in zip(res[False], res[True])), (b, t, ci, co, kk)
+
+
+def test_ring_kernel_matches_emulation(pkg):
+    """csrc/conv1d_ring.hip (LDS-DMA ring, bf16, c_in % 64 == 0, k >= 2): tiles that span many short items (halo rows come
+    from the buffer descriptor's zero fill), strides, dilations, ragged masked inputs, partial last tiles and column tiles,
+    and every epilogue; plus the data-gradient form with residual and lrelu' multiplier."""
+    import cl_emul
+    K = pkg.kernels
+    torch.manual_seed(11)
+    dtype, tol = torch.bfloat16, 1.5e-2
+    cases = [  # b, t, c_in, c_out, k, stride, dil, pad
+        (80, 7, 1024, 1024, 5, 1, 1, 2), (352, 10, 1024, 1024, 5, 1, 1, 2), (33, 19, 128, 512, 5, 3, 1, 2), (64, 51, 256, 320, 5, 1, 1, 2),
+        (96, 102, 128, 512, 5, 3, 1, 2), (3, 700, 192, 384, 5, 1, 1, 2), (2, 2048, 128, 128, 11, 1, 5, 25), (16, 256, 256, 256, 7, 1, 3, 9),
+        (5, 301, 64, 96, 3, 1, 1, 1), (1, 130, 512, 70, 2, 1, 1, 0), (7, 33, 320, 200, 41, 4, 1, 20), (32, 32, 1024, 1024, 5, 1, 1, 2),
+    ]
+    for (b, t, ci, co, kk, st, dl, pd) in cases:
+        x = torch.randn(b, t, ci, device=DEV).to(dtype)
+        w = (torch.randn(kk, co, ci, device=DEV) / (ci * kk) ** 0.5).to(dtype)
+        bias = torch.randn(co, device=DEV)
+        lens = torch.randint(1, t + 1, (b,), device=DEV, dtype=torch.int32)
+        kw = dict(bias=bias, pad=pd, stride=st, dil=dl, out_slope=0.2, lengths=lens, flags=K.CONV_MASK_IN)
+        ya, yb = K.conv1d_cl_raw(x, w, **kw), cl_emul.conv1d_cl_raw(x, w, **kw)
+        assert ya.shape == yb.shape and rel(ya, yb) < tol, ("fwd", b, t, ci, co, kk, st, dl)
+        kwi = dict(kw, in_slope=0.1)
+        assert rel(K.conv1d_cl_raw(x, w, **kwi), cl_emul.conv1d_cl_raw(x, w, **kwi)) < tol, ("in_slope", b, t, ci, co, kk, st, dl)
+        r, mg = torch.randn_like(ya), torch.randn_like(ya)
+        bias_b = torch.randn(b, co, device=DEV)
+        kw2 = dict(bias_b=bias_b, res=r, mg_src=mg, mg_slope=0.1, pad=pd, stride=st, dil=dl, out_scale=0.5, lengths=lens, flags=K.CONV_MASK_OUT)
+        assert rel(K.conv1d_cl_raw(x, w, **kw2), cl_emul.conv1d_cl_raw(x, w, **kw2)) < tol, ("epilogue", b, t, ci, co, kk, st, dl)
+        oa, ob = ya.clone(), yb.clone()
+        K.conv1d_cl_raw(x, w, res=r, out=oa, pad=pd, stride=st, dil=dl, flags=K.CONV_ACCUM | K.CONV_RES_AFTER | K.CONV_TANH)
+        cl_emul.conv1d_cl_raw(x, w, res=r, out=ob, pad=pd, stride=st, dil=dl, flags=K.CONV_ACCUM | K.CONV_RES_AFTER | K.CONV_TANH)
+        assert rel(oa, ob) < tol, ("accum", b, t, ci, co, kk, st, dl)
+        kw3 = dict(bias=bias, res=r, mg_src=mg, mg_slope=0.1, pad=pd, stride=st, dil=dl, lengths=lens, flags=K.CONV_MASK_OUT | K.CONV_RES_AFTER)
+        assert rel(K.conv1d_cl_raw(x, w, **kw3), cl_emul.conv1d_cl_raw(x, w, **kw3)) < tol, ("res_after", b, t, ci, co, kk, st, dl)
+        kw4 = dict(res=r, mg_src=mg, mg_slope=0.1, pad=pd, stride=st, dil=dl)                # the discriminators' data-gradient form
+        assert rel(K.conv1d_cl_raw(x, w, **kw4), cl_emul.conv1d_cl_raw(x, w, **kw4)) < tol, ("dgrad form", b, t, ci, co, kk, st, dl)
+        assert torch.equal(K.conv1d_cl_raw(x, w, **kw), ya)                      # reproducible
