@@ -29,15 +29,24 @@ import torch.distributed as dist
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def cpu_baseline(hps, cfgs, seconds_budget=25.0):
-    """The CPU path timed on this box's host cores (rank 0, N=1 only): the oracle's torch-cpu fp32
-    restatement of the same step + the C alignment DP (kind "port"), on a bounded sample:
-    batch 2, T_y = (120, 96) frames, as many steps as fit the budget (>= 1)."""
+def cpu_baseline(cfgs, seconds_budget=40.0, threads=16):
+    """The CPU path timed on this box's host cores (rank 0, N = 1 only), on BASELINE config C1's shapes
+    (configs/finetune_speaker.json: n_speakers = 999, batch 2, T_y = (400, 320), T_x = (161, 129)): the oracle's torch-cpu fp32
+    restatement of the same step (kind "port": the reference script asserts CUDA and cannot run on a CPU, and its sources do
+    not travel to the GPU box) — one warm-up step, then the median of the steps that fit the budget (up to 6).  The alignment DP
+    is timed separately on ONE core (the reference build has no OpenMP): the reference's own Cython routine compiled into
+    oracle/_ref when that is present, else the C restatement."""
+    import statistics
     from importlib import import_module
+    import numpy as np
     from oracle import vits_torch as O
+    from oracle import mas as omas
     tr = import_module("personalized_text-to-speech_amd.train")
     P = import_module("personalized_text-to-speech_amd")
+    name, B, t_y = cfgs.WORKLOADS["C1"]
+    hps = cfgs.get(name)
     torch.manual_seed(0)
+    torch.set_num_threads(threads)           # the GPU box's CPU share for one GPU (torch-cpu oversubscribes badly on all 128 hardware threads)
     m = {k: v for k, v in hps.model.items()}
     g = P.SynthesizerTrn(hps.n_symbols, hps.data.filter_length // 2 + 1, hps.train.segment_size // hps.data.hop_length,
                          n_speakers=hps.data.n_speakers, **m)
@@ -47,13 +56,12 @@ def cpu_baseline(hps, cfgs, seconds_budget=25.0):
     del g, d
     opt_g = torch.optim.AdamW([v for v in sd_g.values() if v.requires_grad], hps.train.learning_rate, betas=hps.train.betas, eps=hps.train.eps)
     opt_d = torch.optim.AdamW(list(sd_d.values()), hps.train.learning_rate, betas=hps.train.betas, eps=hps.train.eps)
-    B = 2
-    batch = tr.synthetic_batch(hps, B, (96, 120), "cpu",
+    batch = tr.synthetic_batch(hps, B, t_y, "cpu",
                                spec_fn=lambda w: O.spectrogram(w, hps.data.filter_length, hps.data.hop_length, hps.data.win_length))
     x, spec = batch[0], batch[2]
     hp = dict(hps.data); hp.update(hps.train)
-    H, T_x = hps.model.hidden_channels, x.size(1)
-    steps, t_total = 0, 0.0
+    T_x = x.size(1)
+    times, t_total = [], 0.0
     while True:
         noise = [torch.randn(B, hps.model.inter_channels, spec.size(2)), torch.randn(B, 2, T_x), torch.rand(B)]
         t0 = time.perf_counter()
@@ -61,12 +69,93 @@ def cpu_baseline(hps, cfgs, seconds_budget=25.0):
         opt_d.zero_grad(); loss_disc.backward(); opt_d.step()
         loss_gen_all, _ = O.generator_losses(sd_d, hp, *rest)
         opt_g.zero_grad(); loss_gen_all.backward(); opt_g.step()
-        t_total += time.perf_counter() - t0
-        steps += 1
-        if t_total > seconds_budget or steps >= 8:
+        dt = time.perf_counter() - t0
+        times.append(dt)
+        t_total += dt
+        if len(times) >= 6 or (len(times) >= 2 and t_total > seconds_budget):
             break
-    return dict(value=B * hps.train.segment_size * steps / t_total, unit="samples/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"oracle torch-cpu fp32 step + C alignment DP, batch {B}, T_y=(120,96), {steps} step(s), {t_total:.1f} s")
+    timed = times[1:]                                    # the first step is the warm-up
+    step_s = statistics.median(timed)
+    # alignment DP on one core: C1's shape and C3's (b = 64, 800 x 321)
+    dp = {}
+    fn, kind = omas.mas_port, "port (oracle/mas_ref.c)"
+    try:
+        if omas.have_reference():
+            fn, kind = omas.mas_reference, "reference (core.pyx compiled into oracle/_ref)"
+    except Exception:
+        pass
+    rng = np.random.default_rng(0)
+    for tag, (bb, ty, tx) in dict(c1=(2, 400, 161), c3=(64, 800, 321)).items():
+        nc = rng.standard_normal((bb, ty, tx)).astype(np.float32)
+        t_ys, t_xs = np.full(bb, ty, np.int32), np.full(bb, tx, np.int32)
+        fn(nc, t_ys, t_xs)
+        reps = []
+        for _ in range(5):
+            t0 = time.perf_counter(); fn(nc, t_ys, t_xs); reps.append(time.perf_counter() - t0)
+        dp[tag] = dict(shape=[bb, ty, tx], ms=statistics.median(reps) * 1e3, Mcell_per_s=bb * ty * tx / statistics.median(reps) / 1e6)
+    return dict(value=B * hps.train.segment_size / step_s, unit="samples/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"C1 shapes (finetune_speaker.json, batch {B}, T_y=(400,320), T_x={T_x}): oracle torch-cpu fp32 step + alignment DP, "
+                       f"median of {len(timed)} step(s) after 1 warm-up, {step_s:.2f} s/step, {t_total:.1f} s in all",
+                alignment_dp=dict(cores=1, kind=kind, **dp))
+
+
+def secondary_fp32(tr, hps, device, batch, batch_size):
+    """The same workload in the fp32 parity mode (the mode that meets BASELINE.json's 1e-3 tolerance): eager launches,
+    1 warm-up + 3 timed steps.  Reported beside the bf16 headline, never as `value`."""
+    ft = tr.FineTuner(hps, device, amp=False)
+    ft.step(batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        ft.step(batch)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    del ft
+    torch.cuda.empty_cache()
+    return dict(fp32_ms_per_step=dt * 1e3, fp32_samples_per_s=batch_size * hps.train.segment_size / dt, execution="eager launches, 3 steps")
+
+
+def bench_infer(args, P, cfgs, device):
+    """--workload C4 (BASELINE.json configs[3]): SynthesizerTrn.infer() on 32 prompts of 513 tokens, durations forced to 861
+    frames (10.0 s at 22.05 kHz) per item; value = generated waveform samples per second (eager launches, one GPU)."""
+    hps = cfgs.get(cfgs.C4["config"])
+    torch.manual_seed(hps.train.seed)
+    g = P.SynthesizerTrn(hps.n_symbols, hps.data.filter_length // 2 + 1, hps.train.segment_size // hps.data.hop_length,
+                         n_speakers=hps.data.n_speakers, **hps.model).to(device).eval()
+    x, xl, sid, dur = cfgs.c4_inputs(hps, device)
+    ac = torch.autocast("cuda", dtype=torch.bfloat16, enabled=not args.fp32)
+
+    def step():
+        with torch.no_grad(), ac:
+            return g.infer(x, xl, sid=sid, noise_scale=cfgs.C4["noise_scale"], noise_scale_w=cfgs.C4["noise_scale_w"], durations=dur)[0]
+
+    for _ in range(args.warmup):
+        o = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        o = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    assert bool(torch.isfinite(o).all())
+    P._lib.timer.enabled = True; P._lib.timer.reset()
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    P._lib.timer.enabled = False
+    summ = P._lib.timer.summary()
+    per_kernel = {n: dict(launches_per_step=sm["calls"] / 2, ms_per_step=sm["total_ms"] / 2, avg_launch_us=sm["avg_ms"] * 1e3,
+                          algorithmic_GBps=sm["units_total"][1] / (sm["total_ms"] * 1e-3) / 1e9) for n, sm in summ.items()}
+    dom = max(per_kernel, key=lambda k: per_kernel[k]["ms_per_step"])
+    roof = dict(kernel=dom, bound="hbm", achieved=per_kernel[dom]["algorithmic_GBps"], peak=HBM_PEAK_GBS, unit="GB/s",
+                frac=per_kernel[dom]["algorithmic_GBps"] / HBM_PEAK_GBS, traffic=None, avg_launch_us=per_kernel[dom]["avg_launch_us"],
+                all_kernels=per_kernel)
+    samples = o.size(0) * o.size(-1) * args.steps
+    return dict(metric="22.05 kHz waveform samples/sec, VITS infer()", value=samples / elapsed, unit="samples/s", n_gpus=1,
+                steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True, scaling="weak",
+                vs_baseline=None, dtype="fp32" if args.fp32 else "bf16", data="synthetic",
+                config=dict(workload=f"C4: infer(), batch {o.size(0)}, T_x = {x.size(1)} tokens, {o.size(-1)} samples per item (durations forced)",
+                            parallelism="dp1", execution="eager launches"), roofline=roof)
 
 
 def main():
@@ -77,6 +166,7 @@ def main():
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--fp32", action="store_true", help="parity mode: no bf16 autocast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the fp32 (parity mode) timing reported next to the bf16 headline")
     ap.add_argument("--segmented", action="store_true", help="force the three-graph (data-parallel) form of the captured step at N = 1")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying the captured hipGraph")
     args = ap.parse_args()
@@ -105,6 +195,11 @@ def main():
     tr = import_module("personalized_text-to-speech_amd.train")
     P._lib.lib()                                          # fail loudly if the HIP library is missing
 
+    if args.workload == "C4":
+        if world != 1:
+            raise SystemExit("workload C4 (inference) runs as independent replicas: launch it with --gpus 1 per GPU")
+        print(json.dumps(bench_infer(args, P, cfgs, device)))
+        return
     cfg_name, batch_size, t_y_range = cfgs.WORKLOADS[args.workload]
     hps = cfgs.get(cfg_name)
     tuner = tr.FineTuner(hps, device, amp=not args.fp32)
@@ -224,8 +319,10 @@ def main():
                                 parallelism=f"dp{world}", execution=("hipGraph replay" if world == 1 and not args.segmented else "three hipGraphs, gradient all-reduce between them") if use_graph else "eager launches",
                                 kernels=P.kernels.BACKENDS, losses=losses),
                     roofline=roof)
+        if world == 1 and not args.fp32 and not args.no_secondary:
+            line["secondary"] = secondary_fp32(tr, hps, device, batch, batch_size)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(hps, cfgs)
+            line["cpu_baseline"] = cpu_baseline(cfgs)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -49,3 +49,21 @@ WORKLOADS = {
     "C3": ("uma_trilingual", 64, (300, 800)),
     "C5": ("hires48k", 8, (300, 600)),
 }
+# C4 (BASELINE.json configs[3]): inference only — batch 32, 256-phoneme prompts (T_x = 513 with blanks), durations forced to
+# the pattern 2,2,1 over the tokens so that every item is 861 frames = 220 416 samples (10.0 s at 22.05 kHz)
+C4 = dict(config="finetune_speaker", batch=32, t_x=513, frames=861, noise_scale=0.667, noise_scale_w=0.8)
+
+
+def c4_inputs(hps, device, seed=1234):
+    """(x, x_lengths, sid, durations) of workload C4 (seeded)."""
+    import torch
+    gen = torch.Generator().manual_seed(seed)
+    b, t_x, frames = C4["batch"], C4["t_x"], C4["frames"]
+    x = torch.zeros(b, t_x, dtype=torch.long)
+    x[:, 1::2] = torch.randint(1, hps.n_symbols, (b, t_x // 2), generator=gen)
+    dur = torch.tensor([2, 2, 1] * (t_x // 3 + 1))[:t_x].float()
+    extra = frames - int(dur.sum())                       # 513 tokens of 2,2,1 give 855 frames: the first tokens take the rest
+    dur[:extra] += 1
+    assert int(dur.sum()) == frames
+    return (x.to(device), torch.full((b,), t_x, dtype=torch.long, device=device), (torch.arange(b) % 10).to(device),
+            dur.view(1, 1, t_x).expand(b, 1, t_x).contiguous().to(device))

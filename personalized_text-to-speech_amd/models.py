@@ -538,9 +538,11 @@ class SynthesizerTrn(nn.Module):
         with self._scope():
             return self._forward(x, x_lengths, y, y_lengths, sid)
 
-    def infer(self, x, x_lengths, sid=None, noise_scale=1, length_scale=1, noise_scale_w=1.0, max_len=None):
+    def infer(self, x, x_lengths, sid=None, noise_scale=1, length_scale=1, noise_scale_w=1.0, max_len=None, durations=None):
+        """Reference signature (models.py:499) plus `durations` [b, 1, t_x] (optional, not in the reference): frames per token
+        to use instead of ceil(exp(logw)) — benchmark harnesses force a fixed utterance length with it."""
         with self._scope():
-            return self._infer(x, x_lengths, sid, noise_scale, length_scale, noise_scale_w, max_len)
+            return self._infer(x, x_lengths, sid, noise_scale, length_scale, noise_scale_w, max_len, durations)
 
     def voice_conversion(self, y, y_lengths, sid_src, sid_tgt):
         with self._scope():
@@ -574,7 +576,7 @@ class SynthesizerTrn(nn.Module):
         o = self.dec(z_slice, g=g)
         return o, l_length, attn, ids_slice, x_mask, y_mask, (z, z_p, m_p, logs_p, m_q, logs_q)
 
-    def _infer(self, x, x_lengths, sid=None, noise_scale=1, length_scale=1, noise_scale_w=1.0, max_len=None):
+    def _infer(self, x, x_lengths, sid=None, noise_scale=1, length_scale=1, noise_scale_w=1.0, max_len=None, durations=None):
         x, m_p, logs_p, x_mask = self.enc_p(x, x_lengths)
         g = self._speaker(sid)
         if self.use_sdp:
@@ -582,7 +584,7 @@ class SynthesizerTrn(nn.Module):
         else:
             logw = self.dp(x, x_mask, g=g)
         w = torch.exp(logw) * x_mask * length_scale
-        w_ceil = torch.ceil(w)
+        w_ceil = torch.ceil(w) if durations is None else durations.to(w.dtype) * x_mask
         y_lengths = torch.clamp_min(commons.sum12(w_ceil), 1).long()
         y_mask = torch.unsqueeze(commons.sequence_mask(y_lengths, None), 1).to(x_mask.dtype)
         attn_mask = torch.unsqueeze(x_mask, 2) * torch.unsqueeze(y_mask, -1)
