@@ -260,6 +260,27 @@ class FineTuner:
         self.sched_d.step()
 
 
+def evaluate(hps, generator, batch, max_len=1000):
+    """One evaluation pass of the reference (finetune_speaker_v2.py:313-368) without its TensorBoard plumbing: the first item
+    of `batch` goes through infer(); returns what the reference hands to its writer — the generated waveform cut to its length,
+    its mel, and the ground-truth mel / waveform — and leaves the generator in train mode."""
+    x, x_lengths, spec, spec_lengths, y, y_lengths, speakers = [t[:1] for t in batch]
+    generator.eval()
+    try:
+        with torch.no_grad():
+            y_hat, attn, mask, *_ = generator.infer(x, x_lengths, speakers, max_len=max_len)
+            y_hat_lengths = mask.sum([1, 2]).long() * hps.data.hop_length
+            mel = spec_to_mel_torch(spec.float(), hps.data.filter_length, hps.data.n_mel_channels, hps.data.sampling_rate,
+                                    hps.data.mel_fmin, hps.data.mel_fmax)
+            y_hat_mel = mel_spectrogram_torch(y_hat.squeeze(1).float(), hps.data.filter_length, hps.data.n_mel_channels,
+                                              hps.data.sampling_rate, hps.data.hop_length, hps.data.win_length,
+                                              hps.data.mel_fmin, hps.data.mel_fmax)
+    finally:
+        generator.train()
+    return {"gen/mel": y_hat_mel[0], "gen/audio": y_hat[0, :, :int(y_hat_lengths[0])], "gt/mel": mel[0],
+            "gt/audio": y[0, :, :int(y_lengths[0])], "attn": attn[0, 0]}
+
+
 def synthetic_batch(hps, batch_size, t_y_range, device, seed=1234, rank=0, spec_fn=None):
     """Deterministic synthetic minibatch of SURVEY.md §8(d): lengths linspace(lo, hi) sorted
     descending (TextAudioSpeakerCollate, data_utils.py:129-131), text ids with interspersed blanks
