@@ -390,6 +390,10 @@ __global__ void reduce_pending_kernel(PendingTable tab) {
   }
 }
 
+// upper bound of the (b,t) splits: narrow layers (one or a few 64 x 64 tiles: the last decoder stages) need many splits to put
+// 2-3 workgroups on every CU — their chunks are latency-bound — and their slabs are tiny (k * 32 * 32 floats)
+constexpr int kMaxSplits = 256;
+
 int taps_per_group(int k) { return k <= 4 ? k : (k <= 8 ? (k + 1) / 2 : 4); }
 
 // Number of (b,t)-reduction splits: enough workgroups to fill the chip (together with the tile and tap-group
@@ -404,7 +408,7 @@ int pick_splits(int b, int t_out, int c_in, int c_out, int k, bool flat = false)
   const int s_traffic = (int)(io_elems / dw_elems) + 1;                // slab bytes <= 4x activation bytes (measured: for these
                                                                        // small layers parallelism beats the extra slab traffic)
   if (s > s_traffic) s = s_traffic;
-  if (s > 64) s = 64;
+  if (s > kMaxSplits) s = kMaxSplits;
   if (s > chunks) s = chunks;
   if (s < 1) s = 1;
   return s;
