@@ -26,7 +26,6 @@
 // Fused epilogue (flags): + bias[co] + bias_b[b][co] (speaker conditioning) + residual, * scale,
 // * leaky-relu'(src) (chain rule of a fused input activation, for the data-gradient call),
 // residual after the multiplier (skip connection of a data gradient), row mask, tanh, accumulate.
-#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -332,6 +331,27 @@ __global__ __launch_bounds__(kThreads) void conv1d_cl_kernel(ConvArgs args) {
     return;
   }
 
+  // the common epilogue (bias, scale, output leaky-relu, output mask: no memory operand besides the bias) without a flag test
+  // per element — most of the step's ~400 small launches end here, and the generic loop below spends a branch per flag per element
+  if (!R && !MG && !a.bias_b && !(a.flags & (VITS_CONV_ACCUM | VITS_CONV_TANH | VITS_CONV_GATE_BWD))) {
+    const float oslope = (a.flags & VITS_CONV_OUT_LRELU) ? a.out_slope : 1.0f;
+    const int t_hi = ((a.flags & VITS_CONV_MASK_OUT) && len < Tout) ? len : Tout;     // rows >= t_hi (and < Tout) are written as zero
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int co = co0 + (wn * NT + n) * 32 + r;
+      if (co >= a.c_out) continue;
+      const float bsum = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int t = t0 + wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (t >= Tout) continue;
+        float v = (acc[n][i] + bsum) * a.out_scale;
+        v = v > 0.f ? v : v * oslope;
+        Y[(size_t)t * a.ldy + co] = from_f<T>(t < t_hi ? v : 0.f);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     const int co = co0 + (wn * NT + n) * 32 + r;
@@ -380,14 +400,7 @@ int launch_conv(const vits_conv_desc& d, int t_out, hipStream_t s) {
   const size_t lds = (size_t)xrows * PITCHK + (size_t)G * TN * PITCHK;
   if (lds > (size_t)vits::kLdsBytesMax) return VITS_E_UNSUPPORTED;
   auto kern = conv1d_cl_kernel<T, NT, WM, NC>;
-  // once per kernel instance, to the hardware maximum: a per-launch value would be whatever the LAST call set by
-  // the time a captured graph replays its nodes
-  static bool lds_attr_set = false;
-  if (!lds_attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, vits::kLdsBytesMax);
-    if (e != hipSuccess) return vits::note_hip_error(e, "vits_conv1d_cl/attr");
-    lds_attr_set = true;
-  }
+  { const hipError_t e = vits::ensure_max_dynamic_lds(reinterpret_cast<const void*>(kern)); if (e != hipSuccess) return vits::note_hip_error(e, "vits_conv1d_cl/attr"); }
   const bool gate = (d.flags & VITS_CONV_GATE) != 0;
   const int cols = gate ? d.gate_h : d.c_out;
   dim3 grid(vits::ceil_div(t_out, TMW), vits::ceil_div(cols, gate ? TN / 2 : TN), d.b);
@@ -406,17 +419,6 @@ int dispatch_tile(const vits_conv_desc& d, int t_out, hipStream_t s) {
   if (gate) {                                    // needs an even number of tiles per wave
     if (wgs(128, 128) >= want || cols <= 64) return launch_conv<T, 4, 4>(d, t_out, s);
     return launch_conv<T, 2, 2>(d, t_out, s);    // 64 rows x (2 waves x 64 columns)
-  }
-  if constexpr (sizeof(T) == 2) {
-    // single-stage form for the 1x1 layers with 65..192 input channels (see the kernel's NC): 64-row tiles keep the LDS
-    // footprint at (64 + TN) * 400 B, i.e. two or more workgroups per CU
-    // measured: correct (tests pass with it on) but the step is SLOWER (50.9 vs 49.7 ms): fewer tile shapes and ~200 VGPRs cost
-    // more than the two saved load round trips; opt-in for further experiments
-    static const bool wide = getenv("VITS_CONV_WIDE") && getenv("VITS_CONV_WIDE")[0] == '1';
-    if (wide && d.k == 1 && d.stride == 1 && d.c_in > 64 && d.c_in <= 192) {
-      if (cols > 64) return launch_conv<T, 2, 2, 3>(d, t_out, s);     // 64 x 128
-      if (cols > 32) return launch_conv<T, 1, 2, 3>(d, t_out, s);     // 64 x 64
-    }
   }
   if (cols > 64 && wgs(128, 128) >= want) return launch_conv<T, 4, 4>(d, t_out, s);
   if (cols > 64 && wgs(64, 128) >= want) return launch_conv<T, 2, 2>(d, t_out, s);
@@ -462,11 +464,10 @@ extern "C" int vits_conv1d_cl(const vits_conv_desc* desc, void* stream) {
   if (d.groups > 1 && (d.c_out % d.groups != 0 || d.c_in % d.groups != 0)) return VITS_E_BADARG;
   const bool must_flat = in_div > 1 || (d.flags & VITS_CONV_FLAT) != 0 || d.groups > 1;
   if (must_flat && !flat_ok) return VITS_E_UNSUPPORTED;
-  static const bool auto_flat = !(getenv("VITS_FLAT_AUTO") && getenv("VITS_FLAT_AUTO")[0] == '0');
+  const bool auto_flat = true;
   // deep-prefetch ring kernel (csrc/conv1d_ring.hip) for layers with >= 128 input channels and k >= 2: measured faster than or
   // equal to the one-stage-ahead kernels on every such shape of the step (tools/ubench_conv.py; 2.3x on the 1024-channel layers)
-  static const int ring_mode = getenv("VITS_RING") ? atoi(getenv("VITS_RING")) : 1;             // 0 = off (A/B measurements)
-  if (ring_mode && d.dtype == VITS_DT_BF16 && flat_ok && in_div == 1 && d.groups <= 1 && d.k >= 2 && d.c_in >= 128 && d.c_out >= 96) {
+  if (d.dtype == VITS_DT_BF16 && flat_ok && in_div == 1 && d.groups <= 1 && d.k >= 2 && d.c_in >= 128 && d.c_out >= 96) {
     const int rc = vits::conv1d_ring_dispatch(d, t_out, s);
     if (rc != VITS_E_UNSUPPORTED) return rc;
   }

@@ -15,7 +15,6 @@
 // accumulator per tap); the next chunk's tiles are prefetched into registers during the MFMAs.  The (b, t) reduction is split over blockIdx.x; every split writes its own
 // fp32 slab and a second kernel sums the slabs in a fixed order (bitwise reproducible — no float
 // atomics, cdna_hip_programming.md Guideline 12).
-#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -421,14 +420,7 @@ int launch(const WgradArgs& a, hipStream_t s) {
   if (SMALL && lds < (size_t)3 * KT * 16 * 64 * 4) lds = (size_t)3 * KT * 16 * 64 * 4;
   if (lds > (size_t)vits::kLdsBytesMax - 256) return VITS_E_UNSUPPORTED;      // minus the kernel's static LDS
   auto kern = wgrad_kernel<T, KT, SMALL, FLAT>;
-  // once per kernel instance, to the hardware maximum: a per-launch value would be whatever the LAST call set by
-  // the time a captured graph replays its nodes
-  static bool lds_attr_set = false;
-  if (!lds_attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, vits::kLdsBytesMax - 256);
-    if (e != hipSuccess) return vits::note_hip_error(e, "vits_conv1d_cl_wgrad/attr");
-    lds_attr_set = true;
-  }
+  { const hipError_t e = vits::ensure_max_dynamic_lds(reinterpret_cast<const void*>(kern), 256); if (e != hipSuccess) return vits::note_hip_error(e, "vits_conv1d_cl_wgrad/attr"); }
   dim3 grid(a.S, vits::ceil_div(a.Cout, CT), (a.groups > 1 ? 1 : vits::ceil_div(a.Cin, CT)) * vits::ceil_div(a.K, KT));
   hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, s, a);
   return vits::check_launch("vits_conv1d_cl_wgrad");
@@ -506,7 +498,7 @@ static int wgrad_impl(const vits_wgrad_desc* desc, void* stream, vits_wgrad_pend
   if (d.lddy <= 0) d.lddy = d.c_out;
   // flat-row variant: strided layers and many short items (same rule as vits_conv1d_cl); never more splits than the
   // per-item variant, so the workspace bound above holds for both
-  static const bool auto_flat = !(getenv("VITS_FLAT_AUTO") && getenv("VITS_FLAT_AUTO")[0] == '0');
+  const bool auto_flat = true;
   if (d.groups > 1) {
     // block-diagonal tiles only: a 64-wide co tile must map into ONE 64-wide ci tile
     if (d.c_out % d.groups != 0 || d.c_in % d.groups != 0) return VITS_E_BADARG;

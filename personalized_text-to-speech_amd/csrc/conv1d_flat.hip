@@ -10,7 +10,6 @@
 //     rows are enumerated phase-major (t mod s), so inside a tile only the taps with
 //     (phase + tap*dil - pad') % s == 0 are non-zero and the others are skipped entirely (no zero-insertion,
 //     no wasted MFMAs).
-#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -287,14 +286,7 @@ int launch_flat(const vits_conv_desc& d, int t_out, hipStream_t s) {
   const size_t lds = (size_t)G * (TMW + TN) * PITCH;
   if (lds > (size_t)vits::kLdsBytesMax - 1024) return VITS_E_UNSUPPORTED;
   auto kern = conv1d_flat_kernel<T, NT, WM, WR>;
-  // once per kernel instance, to the hardware maximum: a per-launch value would be whatever the LAST call set by
-  // the time a captured graph replays its nodes
-  static bool lds_attr_set = false;
-  if (!lds_attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, vits::kLdsBytesMax - 1024);   // minus the static taplist
-    if (e != hipSuccess) return vits::note_hip_error(e, "vits_conv1d_flat/attr");
-    lds_attr_set = true;
-  }
+  { const hipError_t e = vits::ensure_max_dynamic_lds(reinterpret_cast<const void*>(kern), 1024); if (e != hipSuccess) return vits::note_hip_error(e, "vits_conv1d_flat/attr"); }   // minus the static taplist
   dim3 grid(args.phases * args.tiles_per_phase, vits::ceil_div(d.c_out, TN), 1);
   hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, s, args);
   return vits::check_launch("vits_conv1d_cl(flat)");
@@ -309,13 +301,11 @@ int conv1d_flat_dispatch(const vits_conv_desc& d, int t_out, hipStream_t s) {
   if (d.k > KMAX) return VITS_E_UNSUPPORTED;
   const long rows = (long)d.b * t_out;
   if (d.dtype == VITS_DT_BF16) {
-    static const int big = getenv("VITS_FLAT_BIG") ? atoi(getenv("VITS_FLAT_BIG")) : 0;       // measured: the 64x64-per-wave variant is
-    // SLOWER for the step (53.2 vs 52.1 ms): these layers are bound by load latency at 2 workgroups per CU, not by LDS reads
-    if (d.c_out > 64 && big == 2 && rows >= 2048) return launch_flat<__bf16, 2, 2, 2>(d, t_out, s);                // 128 x 128, 64 x 64 per wave
+    // (measured and dropped: a 64x64-per-wave variant, launch_flat<__bf16, 2, 2, 2>, was slower for the step — 53.2 vs 52.1 ms)
     if (d.c_out > 64 && rows * ((d.c_out + 127) / 128) >= 128 * 512) return launch_flat<__bf16, 4, 4>(d, t_out, s);   // 128 x 128
     // 64 x 64 tiles when 64 x 128 would leave CUs idle, and for grouped layers (one 64-channel chunk per tile, 41 taps: more
     // taps per stage and twice the workgroups)
-    static const bool small = !(getenv("VITS_FLAT_SMALL") && getenv("VITS_FLAT_SMALL")[0] == '0');
+    const bool small = true;
     const long wgs_64x128 = ((rows + 63) / 64) * ((d.c_out + 127) / 128);
     if (d.c_out > 64 && small && (d.groups > 1 || wgs_64x128 < 320)) return launch_flat<__bf16, 1, 2>(d, t_out, s);
     if (d.c_out > 64) return launch_flat<__bf16, 2, 2>(d, t_out, s);                                               // 64 x 128

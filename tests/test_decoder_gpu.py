@@ -116,3 +116,26 @@ def test_other_baseline_configs_take_a_finite_training_step(pkg, workload, batch
     assert all(np.isfinite(list(out.values()))), out
     missing = [n for n, p in ft.net_g.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all()]
     assert not missing, missing[:5]
+
+
+def test_resblock2_decoder(pkg):
+    """The ResBlock2 branch of the fused decoder (reference modules.py:232-256; no shipped config selects it, models.py:251
+    does): one convolution per unit with the skip connection, against the oracle in fp32 — outputs and all gradients."""
+    torch.manual_seed(11)
+    cfg_model = dict(resblock="2", resblock_kernel_sizes=[3, 5], resblock_dilation_sizes=[[1, 3], [1, 3]], upsample_rates=[4, 4],
+                     upsample_initial_channel=32, upsample_kernel_sizes=[8, 8], inter_channels=16, gin_channels=8)
+    dec = pkg.models.Generator(16, "2", cfg_model["resblock_kernel_sizes"], cfg_model["resblock_dilation_sizes"], cfg_model["upsample_rates"],
+                               32, cfg_model["upsample_kernel_sizes"], gin_channels=8).to(DEV)
+    with torch.no_grad():
+        for p in dec.parameters():
+            p.add_(torch.randn_like(p) * 0.05)
+
+    class Net:
+        pass
+    net = Net()
+    net.dec = dec
+    z = torch.randn(2, 16, 11, device=DEV)
+    g = torch.randn(2, 8, 1, device=DEV)
+    got, yard, y_p = run_both(pkg, net, cfg_model, z, g, False)
+    assert y_p.shape == (2, 1, 11 * 16)
+    check(got, yard, 1e-5)

@@ -15,7 +15,8 @@ ALL_SHAPES = [  # b, t, c_in, c_out, k, stride, dil, pad, tag
     (16, 500, 384, 192, 5, 1, 1, 2, "WN.dgrad_in"), (16, 500, 192, 384, 5, 1, 1, 2, "WN.in(no gate)"),
     (16, 256, 256, 256, 11, 1, 1, 5, "dec256.k11"), (16, 256, 256, 256, 3, 1, 1, 1, "dec256.k3"),
     (16, 2048, 128, 128, 11, 1, 1, 5, "dec128.k11"), (16, 2048, 128, 128, 3, 1, 5, 5, "dec128.k3d5"), (16, 2048, 128, 128, 7, 1, 1, 3, "dec128.k7"),
-    (16, 4096, 64, 64, 11, 1, 1, 5, "dec64.k11"), (16, 201, 768, 192, 3, 1, 1, 1, "ffn2"), (16, 201, 192, 768, 3, 1, 1, 1, "ffn1"),
+    (16, 4096, 64, 64, 11, 1, 1, 5, "dec64.k11"), (16, 201, 192, 192, 1, 1, 1, 0, "t201.1x1"), (16, 500, 192, 192, 1, 1, 1, 0, "t500.1x1"),
+    (16, 201, 208, 96, 1, 1, 1, 0, "t201.pv"), (16, 201, 768, 192, 3, 1, 1, 1, "ffn2"), (16, 201, 192, 768, 3, 1, 1, 1, "ffn1"),
 ]
 SHAPES = [x for x in ALL_SHAPES if not os.environ.get("UB_ONLY") or x[-1] in os.environ["UB_ONLY"].split(",")]
 N = 32
