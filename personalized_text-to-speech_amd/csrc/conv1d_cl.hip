@@ -467,7 +467,7 @@ extern "C" int vits_conv1d_cl(const vits_conv_desc* desc, void* stream) {
   const bool auto_flat = true;
   // deep-prefetch ring kernel (csrc/conv1d_ring.hip) for layers with >= 128 input channels and k >= 2: measured faster than or
   // equal to the one-stage-ahead kernels on every such shape of the step (tools/ubench_conv.py; 2.3x on the 1024-channel layers)
-  if (d.dtype == VITS_DT_BF16 && flat_ok && in_div == 1 && d.groups <= 1 && d.k >= 2 && d.c_in >= 128 && d.c_out >= 96) {
+  if (d.dtype == VITS_DT_BF16 && flat_ok && d.groups <= 1 && d.k >= 2 && d.c_in >= 128 && d.c_out >= 96) {
     const int rc = vits::conv1d_ring_dispatch(d, t_out, s);
     if (rc != VITS_E_UNSUPPORTED) return rc;
   }

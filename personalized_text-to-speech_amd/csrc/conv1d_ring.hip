@@ -37,10 +37,10 @@ constexpr int NR = 3;                   // W stages in flight in registers
 
 struct RingArgs {
   vits_conv_desc d;
-  int Tout, M;                          // output rows per item; flat rows B * Tout
+  int Tout, M;                          // rows per item of the launch's row space (phases > 1: ceil(Tstore / phases)); flat rows B * Tout
   int XR;                               // LDS rows per X buffer (multiple of 32)
   int n_row_tiles, n_col_tiles;
-  int Lfull;                            // input rows a whole item needs: (Tout-1)*stride + (k-1)*dil + 1
+  int phases, Tstore;                   // data gradient of a stride-`phases` convolution (in_div): see the kernel; Tstore = output rows per item
 };
 
 __device__ __forceinline__ float to_f(__bf16 v) { return (float)v; }
@@ -53,15 +53,28 @@ __global__ __launch_bounds__(kThreads) void conv1d_ring_kernel(RingArgs args) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
   const int r = lane & 31, h = lane >> 5;
-  const int Tout = args.Tout, M = args.M;
-  const int s = a.stride, k = a.k, dil = a.dil;
+  const int M = args.M, dil = a.dil;
 
   // ---- tile of this workgroup (XCD-aware: ids that share an XCD walk the row tiles of one column tile)
   const int nwg = gridDim.x, id = blockIdx.x;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = id & 7;
   const int nid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
-  const int col_tile = nid / args.n_row_tiles, row_tile = nid - col_tile * args.n_row_tiles;
+  const int col_tile = nid / args.n_row_tiles, row_all = nid - col_tile * args.n_row_tiles;
   const int co0 = col_tile * BN;
+  // Data gradient of a stride-P convolution (in_div = P, dil = 1): output row u = phase + P q only sees the taps
+  // tap0 + P j (tap0 = (pad - phase) mod P), whose input row is q + j + delta — i.e. every phase is a stride-1 convolution over q
+  // with its own tap subset, and a tile never mixes phases.  P = 1 is the plain case (phase 0, all taps).
+  const int P = args.phases;
+  const int tiles_per_phase = args.n_row_tiles / P;
+  const int phase = row_all / tiles_per_phase, row_tile = row_all - phase * tiles_per_phase;
+  int tap0 = 0, k = a.k, pad = a.pad, s = a.stride;
+  const int Tout = args.Tout;                              // rows per item in this launch's row space (P > 1: ceil(Tstore / P))
+  if (P > 1) {
+    tap0 = ((a.pad - phase) % P + P) % P;
+    k = tap0 < a.k ? (a.k - tap0 + P - 1) / P : 0;
+    pad = -((phase + tap0 - a.pad) / P);                   // exact division
+    s = 1;
+  }
   const int m0 = row_tile * BM;
 
   // ---- item segments of the tile: segment 0 = rows [t_first, t_first + n0) of item b_first, then whole items, then a tail
@@ -71,13 +84,13 @@ __global__ __launch_bounds__(kThreads) void conv1d_ring_kernel(RingArgs args) {
   const int halo = (k - 1) * dil + 1;
   const int L0 = (n0 - 1) * s + halo;
   const int rows_left = rows_here - n0;
-  const int Lfull = args.Lfull;
+  const int Lfull = (Tout - 1) * s + halo;
 
   unsigned char* const Xb = smem;                                  // [2][XR][128]
   unsigned char* const Wb = smem + (size_t)2 * args.XR * ROWB;     // [2][128][128]
 
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)((size_t)a.b * a.t * a.ldx * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, (int)((size_t)k * a.c_out * a.ldw * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, (int)((size_t)a.k * a.c_out * a.ldw * 2), 0x00020000);
 
   // ---- X fill: slot i of a thread covers LDS row 32 i + tid / 8, 16-byte column tid % 8 (source offset; >= 2^31 = zeros)
   const int XI = args.XR >> 5;
@@ -98,7 +111,7 @@ __global__ __launch_bounds__(kThreads) void conv1d_ring_kernel(RingArgs args) {
         if (nj > Tout) nj = Tout;
       }
       const int item = b_first + j;
-      const int tin = (j == 0 ? t_first * s : 0) - a.pad + o;
+      const int tin = (j == 0 ? t_first * s : 0) - pad + o;
       bool ok = nj > 0 && o < (nj - 1) * s + halo && item < a.b && tin >= 0;
       if (ok) {
         int hi = a.t;
@@ -146,7 +159,7 @@ __global__ __launch_bounds__(kThreads) void conv1d_ring_kernel(RingArgs args) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int n_chunks = a.c_in / 64;
-  const int Q = n_chunks * k;
+  const int Q = n_chunks * k;                              // (k = 0: a phase no tap reaches — zero rows, straight to the epilogue)
   const unsigned wtap = (unsigned)((size_t)a.c_out * a.ldw * 2);   // bytes between taps of W
 
   // Every global load below is UNCONDITIONAL (stages / chunks / X slots that do not exist load from an out-of-range offset and
@@ -154,7 +167,7 @@ __global__ __launch_bounds__(kThreads) void conv1d_ring_kernel(RingArgs args) {
   // back to s_waitcnt vmcnt(0) before every LDS write — which would drain the whole ring each stage.
   u32x4 wreg[NR][4], xreg[XIM];
   auto load_w = [&](int set, int c, int tap) {
-    const unsigned sb = c < n_chunks ? (unsigned)tap * wtap + (unsigned)c * 128u : 0x80000000u;
+    const unsigned sb = c < n_chunks ? (unsigned)(tap0 + P * tap) * wtap + (unsigned)c * 128u : 0x80000000u;
 #pragma unroll
     for (int i = 0; i < 4; ++i) wreg[set][i] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)(woff[i] + sb), 0, 0);
   };
@@ -288,16 +301,19 @@ __global__ __launch_bounds__(kThreads) void conv1d_ring_kernel(RingArgs args) {
       const int row = it * 16 + prow;
       const int m = m0 + pass * 64 + row;
       if (m >= M || co8 >= a.c_out) continue;
+      const int bq = m / Tout, q_ = m - bq * Tout;
+      const int u = phase + P * q_;                          // output row inside the item
+      if (u >= args.Tstore) continue;
       const unsigned char* src = reinterpret_cast<const unsigned char*>(stage) + (size_t)row * EP + cg * 32;
       union { u32x4 u[2]; float f[8]; } v;
       v.u[0] = *reinterpret_cast<const u32x4*>(src);
       v.u[1] = *reinterpret_cast<const u32x4*>(src + 16);
-      const size_t o = (size_t)m * a.ldy + co8;
+      const size_t o = ((size_t)bq * args.Tstore + u) * a.ldy + co8;
       union { u32x4 u; __bf16 e[8]; } rv, gv, out;
       if (R) rv.u = *reinterpret_cast<const u32x4*>(R + o);
       if (MG) gv.u = *reinterpret_cast<const u32x4*>(MG + o);
       bool dead = false;
-      if (mask_out) { const int b = m / Tout, t = m - b * Tout; dead = t >= a.lengths[b]; }
+      if (mask_out) dead = u >= a.lengths[bq];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float rr = R ? to_f(rv.e[e]) : 0.f;
@@ -330,7 +346,10 @@ namespace vits {
 // Called by vits_conv1d_cl (d validated and defaulted, bf16).  Returns VITS_E_UNSUPPORTED when the shape is outside what this
 // kernel handles; the caller then takes the other kernels.
 int conv1d_ring_dispatch(const vits_conv_desc& d, int t_out, hipStream_t s) {
-  if (d.dtype != VITS_DT_BF16 || d.c_in % 64 != 0 || d.k < 2 || d.groups > 1 || d.w_batch_stride != 0 || d.in_div > 1) return VITS_E_UNSUPPORTED;
+  if (d.dtype != VITS_DT_BF16 || d.c_in % 64 != 0 || d.k < 2 || d.groups > 1 || d.w_batch_stride != 0) return VITS_E_UNSUPPORTED;
+  const int P = d.in_div > 1 ? d.in_div : 1;
+  // data gradient of a strided convolution: dil 1, every phase keeps at least one tap, no length masks (the two grids differ)
+  if (P > 1 && (d.stride != 1 || d.dil != 1 || d.k < P || (d.flags & (VITS_CONV_MASK_IN | VITS_CONV_MASK_OUT)))) return VITS_E_UNSUPPORTED;
   if (d.flags & (VITS_CONV_GATE | VITS_CONV_GATE_BWD)) return VITS_E_UNSUPPORTED;
   if (d.y2 != nullptr || d.bias_b != nullptr) return VITS_E_UNSUPPORTED;
   if (d.flags & (VITS_CONV_TANH | VITS_CONV_ACCUM)) return VITS_E_UNSUPPORTED;                 // (rare epilogues stay on the other kernels)
@@ -338,15 +357,16 @@ int conv1d_ring_dispatch(const vits_conv_desc& d, int t_out, hipStream_t s) {
   if (d.ldx % 8 != 0 || d.ldw % 8 != 0) return VITS_E_UNSUPPORTED;
   const size_t xbytes = (size_t)d.b * d.t * d.ldx * 2, wbytes = (size_t)d.k * d.c_out * d.ldw * 2;
   if (xbytes >= (1ull << 31) || wbytes >= (1ull << 31)) return VITS_E_UNSUPPORTED;
-  const long M = (long)d.b * t_out;
-  if (M >= (1l << 30)) return VITS_E_UNSUPPORTED;
+  const int t_rows = (t_out + P - 1) / P;                     // rows per item in one phase
+  const long M = (long)d.b * t_rows;
+  if (M * P >= (1l << 30)) return VITS_E_UNSUPPORTED;
   const int n_col = vits::ceil_div(d.c_out, BN);
   // 128-row tiles when they still fill the chip, else 64-row tiles; too few tiles: the other kernels' smaller tiles win
-  int BM = ((M + 127) / 128) * n_col >= 200 ? 128 : 64;
-  if (((M + 63) / 64) * n_col < 100) return VITS_E_UNSUPPORTED;
-  const int halo = (d.k - 1) * d.dil + 1;
+  int BM = ((M + 127) / 128) * n_col * P >= 200 ? 128 : 64;
+  if (((M + 63) / 64) * n_col * P < 100) return VITS_E_UNSUPPORTED;
+  const int halo = P > 1 ? (d.k + P - 1) / P : (d.k - 1) * d.dil + 1;      // (phases: the longest tap subset)
   auto xrows = [&](int bm) {
-    int nseg = (bm - 1) / t_out + 2;
+    int nseg = (bm - 1) / t_rows + 2;
     if (nseg > d.b) nseg = d.b;
     int rows = d.stride * bm + nseg * (halo - d.stride);
     if (rows < halo) rows = halo;
@@ -356,7 +376,7 @@ int conv1d_ring_dispatch(const vits_conv_desc& d, int t_out, hipStream_t s) {
   auto fits = [&](int xr) { return (size_t)2 * xr * ROWB + (size_t)2 * WSTAGE <= (size_t)vits::kLdsBytesMax && xr <= 32 * XI_MAX; };
   if (!fits(XR) && BM == 128) { BM = 64; XR = xrows(BM); }
   if (!fits(XR)) return VITS_E_UNSUPPORTED;
-  RingArgs args{d, t_out, (int)M, XR, (int)((M + BM - 1) / BM), n_col, (t_out - 1) * d.stride + halo};
+  RingArgs args{d, t_rows, (int)M, XR, P * (int)((M + BM - 1) / BM), n_col, P, t_out};
   const size_t lds = (size_t)2 * XR * ROWB + (size_t)2 * WSTAGE;
   if (XR <= 32 * 6) return BM == 128 ? launch_ring<128, 6>(args, lds, s) : launch_ring<64, 6>(args, lds, s);
   return BM == 128 ? launch_ring<128, 14>(args, lds, s) : launch_ring<64, 14>(args, lds, s);

@@ -327,3 +327,14 @@ def test_ring_kernel_matches_emulation(pkg):
         kw4 = dict(res=r, mg_src=mg, mg_slope=0.1, pad=pd, stride=st, dil=dl)                # the discriminators' data-gradient form
         assert rel(K.conv1d_cl_raw(x, w, **kw4), cl_emul.conv1d_cl_raw(x, w, **kw4)) < tol, ("dgrad form", b, t, ci, co, kk, st, dl)
         assert torch.equal(K.conv1d_cl_raw(x, w, **kw), ya)                      # reproducible
+    # data gradient of a strided convolution (in_div): dY on the short grid, dX on the long one, phase by phase; odd lengths
+    # (the last phase has one row fewer), k < 2 * stride (phases with a single tap), with and without residual / lrelu' multiplier
+    for (b, t_dy, ci, co, kk, st, pd, t_x) in [(96, 34, 512, 128, 5, 3, 2, 102), (33, 12, 1024, 512, 5, 3, 2, 34), (44, 13, 1024, 512, 5, 3, 2, 37),
+                                                 (6, 90, 256, 256, 41, 4, 20, 358), (64, 23, 128, 128, 5, 3, 2, 69), (40, 16, 192, 96, 4, 2, 1, 33)]:
+        dy = torch.randn(b, t_dy, ci, device=DEV).to(dtype)
+        w = (torch.randn(kk, co, ci, device=DEV) / (ci * kk) ** 0.5).to(dtype)
+        r, mg = torch.randn(b, t_x, co, device=DEV).to(dtype), torch.randn(b, t_x, co, device=DEV).to(dtype)
+        for kw in (dict(), dict(res=r, mg_src=mg, mg_slope=0.1), dict(res=r, mg_src=mg, mg_slope=0.1, flags=K.CONV_RES_AFTER, out_scale=0.5)):
+            kw = dict(kw, pad=kk - 1 - pd, in_div=st, t_out=t_x)
+            ya, yb = K.conv1d_cl_raw(dy, w, **kw), cl_emul.conv1d_cl_raw(dy, w, **kw)
+            assert ya.shape == yb.shape and rel(ya, yb) < tol, ("in_div", b, t_dy, ci, co, kk, st, sorted(kw))
