@@ -367,6 +367,34 @@ size_t vits_disc_post_wgrad_workspace(int J, int R, int c_in, int k);
 int vits_disc_post_wgrad(int dtype, const void* dy8, const void* h, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
                          int J, int R, int c_in, int k, int pad, int accumulate, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * AdamW over flat parameter / moment buffers + the global L2 norm of the gradients (csrc/adamw.hip).
+ *
+ * Replaces: torch.optim.AdamW(...).step() as finetune_speaker_v2.py:113-120 constructs it and :213-214 / :230-231 call it
+ *           (through GradScaler.step), and commons.clip_grad_value_(parameters, None) (commons.py:149-164), which with
+ *           clip_value None only returns the total L2 norm of the gradients (finetune_speaker_v2.py:212,229).
+ *   p, m, v      float32 flat buffers (parameters, exp_avg, exp_avg_sq) sharing one offset space; p == NULL: norm only;
+ *   host_entries HOST array: entry i = one contiguous run of `n` gradient floats at device address `g` updating the flat
+ *                offsets [offset, offset + n) (passed on to the kernels by value: nothing is kept after the call returns);
+ *   state        device float[2]: state[0] = learning rate, state[1] = number of completed steps (the bias corrections use
+ *                state[1] + 1); vits_gradnorm_final(bump_step = 1) increments it — run it after the update;
+ *   partials     device float[>= vits_adamw_blocks(entries)] (or NULL): per-workgroup sums of g^2;
+ *   vits_gradnorm_final: norm_out[0] = sqrt(sum of partials[0..n)) in a fixed order (bitwise reproducible).
+ *   Update rule (decoupled weight decay, no amsgrad), t = state[1] + 1:
+ *     p *= 1 - lr*wd;  m += (g - m)(1 - beta1);  v = beta2 v + (1 - beta2) g^2;
+ *     p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const float* g;              /* device: first gradient element of the run */
+  unsigned long long offset;   /* first flat element the run updates */
+  unsigned int n;              /* elements */
+  unsigned int reserved;
+} vits_adamw_entry;
+size_t vits_adamw_blocks(const vits_adamw_entry* host_entries, int n_entries);
+int vits_adamw(float* p, float* m, float* v, const vits_adamw_entry* host_entries, int n_entries, const float* state,
+               double beta1, double beta2, double eps, double weight_decay, float* partials, size_t partials_len, void* stream);
+int vits_gradnorm_final(const float* partials, size_t n, float* norm_out, float* state, int bump_step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,4 +23,5 @@ from . import mel_processing  # noqa: F401
 from . import losses  # noqa: F401
 from . import models  # noqa: F401
 from . import utils  # noqa: F401
+from . import optim  # noqa: F401
 from .models import MultiPeriodDiscriminator, SynthesizerTrn  # noqa: F401

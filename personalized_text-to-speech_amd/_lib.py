@@ -10,7 +10,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvitsmi.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 c_int = ctypes.c_int
 c_void_p = ctypes.c_void_p
@@ -58,6 +58,9 @@ SIGNATURES = {
     "vits_disc_post_dgrad": (c_int, [c_int] + [c_void_p] * 5 + [c_int] * 6 + [c_float, c_void_p]),
     "vits_disc_post_wgrad_workspace": (c_size_t, [c_int] * 4),
     "vits_disc_post_wgrad": (c_int, [c_int] + [c_void_p] * 5 + [c_size_t] + [c_int] * 6 + [c_void_p]),
+    "vits_adamw_blocks": (c_size_t, [c_void_p, c_int]),
+    "vits_adamw": (c_int, [c_void_p] * 4 + [c_int, c_void_p] + [ctypes.c_double] * 4 + [c_void_p, c_size_t, c_void_p]),
+    "vits_gradnorm_final": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_int, c_void_p]),
 }
 
 class ConvDesc(ctypes.Structure):
@@ -73,6 +76,11 @@ class PrepEntry(ctypes.Structure):
     """vits_prep_entry of include/vitsmi.h"""
     _fields_ = [("v", c_void_p), ("g", c_void_p), ("off", ctypes.c_int64), ("off_dv", ctypes.c_int64), ("off_dg", ctypes.c_int64)] + \
                [(n, ctypes.c_int32) for n in ("layout", "c_out", "c_in", "k", "c_out_p", "c_in_p", "row_lo", "n_rows", "row0", "groups")]
+
+
+class AdamwEntry(ctypes.Structure):
+    """vits_adamw_entry of include/vitsmi.h"""
+    _fields_ = [("g", c_void_p), ("offset", ctypes.c_uint64), ("n", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
 
 
 class WgradPending(ctypes.Structure):

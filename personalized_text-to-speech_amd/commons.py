@@ -77,7 +77,10 @@ def grad_norm_l2(parameters):
     grads = [p.grad for p in parameters if p.grad is not None]
     if not grads:
         return torch.zeros(())
-    norms = torch._foreach_norm(grads, 2)
+    if grads[0].is_cuda:
+        from .optim import grad_norm_l2 as hip_norm             # csrc/adamw.hip in norm-only mode (vits_adamw + vits_gradnorm_final)
+        return hip_norm(grads)
+    norms = torch._foreach_norm(grads, 2)                       # host tensors (data-pipeline / unit-test use only)
     return torch.linalg.vector_norm(torch.stack(norms), 2)
 
 

@@ -28,7 +28,7 @@ BACKENDS = {
     "rational_quadratic_spline (+autograd)": "hip",       # rq_spline.hip
     "feature-matching / KL / duration sums, bias + conditioning column sums": "hip",   # reduce.hip
     "element-wise glue, adversarial loss arithmetic, embedding lookups, mel matmul": "rocm",   # PyTorch-ROCm device ops
-    "adamw": "rocm",                      # torch.optim.AdamW(fused=True, capturable=True)
+    "adamw + gradient L2 norm (flat buffers, multi-tensor)": "hip",   # adamw.hip (optim.FlatAdamW)
 }
 
 

@@ -8,15 +8,16 @@ Differences from the reference, none of which changes a result:
     of two DDP wrappers, and D's parameters do not take gradients during the G step (the
     reference computes and all-reduces them there only to zero them at the next iteration,
     finetune_speaker_v2.py:210,218,228);
-  * grad norms are 0-d tensors (commons.grad_norm_l2), discriminator_loss keeps tensors: no
-    host synchronisation inside the step.
+  * AdamW and the logged gradient norm are one multi-tensor HIP pass over flat buffers (optim.FlatAdamW); grad norms are
+    0-d tensors, discriminator_loss keeps tensors: no host synchronisation inside the step.
 """
 import contextlib
 
 import torch
 from torch.nn import functional as F
 
-from . import commons
+from . import commons, weight_arena
+from .optim import FlatAdamW
 from .distributed import GradBuckets, broadcast_parameters
 from .losses import discriminator_loss, feature_loss, generator_loss, kl_loss
 from .mel_processing import mel_spectrogram_torch, spec_to_mel_torch
@@ -36,10 +37,13 @@ class FineTuner:
         self.net_d = MultiPeriodDiscriminator(hps.model.use_spectral_norm).to(self.device)
         broadcast_parameters(self.net_g)
         broadcast_parameters(self.net_d)
-        fused = self.device.type == "cuda"
-        kw = dict(betas=hps.train.betas, eps=hps.train.eps, fused=fused, capturable=fused)
-        self.optim_g = torch.optim.AdamW(self.net_g.parameters(), hps.train.learning_rate, **kw)
-        self.optim_d = torch.optim.AdamW(self.net_d.parameters(), hps.train.learning_rate, **kw)
+        # AdamW + gradient norm as one multi-tensor HIP pass over flat buffers (optim.py, csrc/adamw.hip); the parameters the
+        # weight arenas manage are laid out in the arenas' gradient order, so each arena's gradient buffer is one run
+        kw = dict(betas=tuple(hps.train.betas), eps=hps.train.eps)
+        self.optim_g = FlatAdamW(self.net_g.parameters(), hps.train.learning_rate,
+                                 runs=[weight_arena.param_order(SynthesizerTrn._arena_specs(self.net_g))], **kw)
+        self.optim_d = FlatAdamW(self.net_d.parameters(), hps.train.learning_rate,
+                                 runs=[weight_arena.param_order(MultiPeriodDiscriminator._arena_specs(self.net_d))], **kw)
         self._graph = None
         self.buckets_g = GradBuckets(self.net_g.parameters(), bucket_bytes)
         self.buckets_d = GradBuckets(self.net_d.parameters(), bucket_bytes)
@@ -96,8 +100,8 @@ class FineTuner:
         """Discriminator update, then the generator losses against the UPDATED discriminator and their backward
         (finetune_speaker_v2.py:216-232); D is frozen for this backward."""
         hps, st = self.hps, self._st
-        st["grad_norm_d"] = commons.grad_norm_l2(self.net_d.parameters())
-        self.optim_d.step()
+        self.optim_d.step()                                     # (also leaves the L2 norm of the gradients it consumed)
+        st["grad_norm_d"] = self.optim_d.grad_norm
         for p in self.net_d.parameters():
             p.requires_grad_(False)
         self.buckets_d.enabled(False)
@@ -122,8 +126,8 @@ class FineTuner:
 
     def _phase_c(self):
         out = self._out
-        out["grad_norm_g"] = commons.grad_norm_l2(self.net_g.parameters())
         self.optim_g.step()
+        out["grad_norm_g"] = self.optim_g.grad_norm
         return out
 
     # ---------------------------------------------------------------------------------------------
@@ -185,10 +189,10 @@ class FineTuner:
         return self._static_out
 
     def _state_tensors(self):
-        ts = [p for p in self.net_g.parameters()] + [p for p in self.net_d.parameters()]
+        # every parameter and both moments are views of the optimizers' flat buffers
+        ts = []
         for opt in (self.optim_g, self.optim_d):
-            for st in opt.state.values():
-                ts += [v for v in st.values() if torch.is_tensor(v)]
+            ts += [opt.flat_p, opt.flat_m, opt.flat_v, opt.dev_state]
         return ts
 
     def verify_replay(self, rtol=None):
@@ -206,7 +210,7 @@ class FineTuner:
         ts = self._state_tensors()
         snap = [t.detach().clone() for t in ts]
         rng = torch.cuda.get_rng_state(self.device)
-        params = list(self.net_g.parameters()) + list(self.net_d.parameters())
+        flats = [(self.optim_g.flat_p, snap[0]), (self.optim_d.flat_p, snap[4])]      # every parameter of G / of D
 
         def restore():
             with torch.no_grad():
@@ -220,9 +224,8 @@ class FineTuner:
             torch.cuda.synchronize()
             vals = {k: float(v) for k, v in out.items()}
             with torch.no_grad():
-                vals["param_checksum"] = float(torch.stack([p.detach().double().abs().sum() for p in params]).sum())
-                upd = torch.stack([(p.detach().double() - s.double()).abs().sum() for p, s in zip(params, snap)]).sum()
-                vals["update_checksum"] = float(upd)
+                vals["param_checksum"] = float(sum(p.double().abs().sum() for p, _ in flats))
+                vals["update_checksum"] = float(sum((p.double() - s.double()).abs().sum() for p, s in flats))
             return vals
 
         a = run(self.replay)

@@ -57,8 +57,23 @@ def save_checkpoint(model, optimizer, learning_rate, iteration, checkpoint_path)
     """reference utils.py:183-193"""
     logger.info("Saving model and optimizer state at iteration %s to %s", iteration, checkpoint_path)
     target = model.module if hasattr(model, "module") else model
-    torch.save({"model": target.state_dict(), "iteration": iteration,
-                "optimizer": optimizer.state_dict() if optimizer is not None else None,
+
+    def own_storage(obj):
+        # parameters and optimizer moments may be views of flat buffers (optim.FlatAdamW): written as they are, every tensor
+        # would drag the whole flat storage into the file; the reference's files hold one storage per tensor
+        if torch.is_tensor(obj):
+            return obj.detach().clone()
+        if isinstance(obj, dict):
+            out = type(obj)((k, own_storage(v)) for k, v in obj.items())
+            if hasattr(obj, "_metadata"):
+                out._metadata = obj._metadata                  # (module versions torch's load_state_dict looks at)
+            return out
+        if isinstance(obj, (list, tuple)):
+            return type(obj)(own_storage(v) for v in obj)
+        return obj
+
+    torch.save({"model": own_storage(target.state_dict()), "iteration": iteration,
+                "optimizer": own_storage(optimizer.state_dict()) if optimizer is not None else None,
                 "learning_rate": learning_rate}, checkpoint_path)
 
 

@@ -63,16 +63,24 @@ class Spec:
         self.dw_shape = (self.k, self.c_out, self.c_in // groups) if groups > 1 else self.fwd_shape
 
 
+def param_order(specs):
+    """The parameters behind `specs` in the order their gradients lie in an arena's flat gradient buffer (optim.FlatAdamW lays
+    its flat parameter buffer out the same way, so the whole buffer is ONE run of its update kernel)."""
+    params, seen = [], set()
+    for s in specs:
+        for p in (s.v, s.g):
+            if p is not None and id(p) not in seen:
+                seen.add(id(p))
+                params.append(p)
+    return params
+
+
 class WeightArena:
     def __init__(self, specs, dtype):
         self.specs, self.dtype = specs, dtype
         dev = specs[0].v.device
-        self.params, pidx = [], {}
-        for s in specs:
-            for p in (s.v, s.g):
-                if p is not None and id(p) not in pidx:
-                    pidx[id(p)] = len(self.params)
-                    self.params.append(p)
+        self.params = param_order(specs)
+        pidx = {id(p): i for i, p in enumerate(self.params)}
         # parameter-gradient arena: one region per parameter, torch layout
         self.p_off, off = [], 0
         for p in self.params:

@@ -69,18 +69,30 @@ def _reference(pkg):
             for p in ps:
                 p.grad = avg.clone()
 
+    # Parameters whose gradient is mathematically zero (the attention key bias: softmax is shift-invariant) receive rounding
+    # residue ~1e-7 that AdamW normalises to learning-rate-sized steps of arbitrary sign: not comparable between two runs whose
+    # launches differ in anything (tests/test_step_parity_gpu.py excludes them the same way)
+    live = {}
+    def note(net, tag):
+        gn = {f"{tag}/{k}": float(p.grad.norm()) if p.grad is not None else 0.0 for k, p in net.named_parameters()}
+        top = max(gn.values())
+        for k, v in gn.items():
+            live[k] = live.get(k, False) or v >= 1e-5 * top
+
     for i in range(3):
         for ft, b in zip(fts, batches):
             torch.manual_seed(1000 + i)
             ft._phase_a(b)
         average([ft.net_d for ft in fts])
+        note(fts[0].net_d, "d")
         for ft in fts:
             ft._phase_b()
         average([ft.net_g for ft in fts])
+        note(fts[0].net_g, "g")
         for ft in fts:
             ft._phase_c()
     torch.cuda.synchronize()
-    return fts[0]
+    return fts[0], live
 
 
 def _close(a, b, tol=1e-5):
@@ -95,11 +107,16 @@ def test_two_ranks_match_emulation(pkg, tmp_path, mode):
         if k != "losses":
             assert np.array_equal(r0[k], r1[k]), f"ranks disagree on {k}"
     assert not np.array_equal(r0["losses"], r1["losses"])          # different data per rank
-    ref = _reference(pkg)
+    ref, live = _reference(pkg)
+    assert sum(not v for v in live.values()) <= 4, [k for k, v in live.items() if not v]
     for tag, net in (("g", ref.net_g), ("d", ref.net_d)):
         ps = dict(net.named_parameters())
-        assert _close(r0[f"abs_{tag}"], [float(p.detach().double().abs().sum()) for p in ps.values()]), tag
-        for k in [k for k in r0.files if k.startswith(f"p_{tag}/")]:
+        keep = np.array([live[f"{tag}/{k}"] for k in ps])
+        want = np.array([float(p.detach().double().abs().sum()) for p in ps.values()])
+        rel = np.abs(r0[f"abs_{tag}"] - want) / np.maximum(np.abs(want), 1e-3) * keep
+        worst = np.argsort(-rel)[:5]
+        assert np.all(rel <= 1e-5), (tag, [(list(ps)[i], float(rel[i]), float(want[i])) for i in worst], int((rel > 1e-5).sum()), len(rel))
+        for k in [k for k in r0.files if k.startswith(f"p_{tag}/") and live[f"{tag}/{k[4:]}"]]:
             want = ps[k[4:]].detach().cpu().numpy()
             assert np.abs(r0[k] - want).max() <= 1e-5 * max(np.abs(want).max(), 1e-3), k
 
