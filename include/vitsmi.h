@@ -395,6 +395,30 @@ int vits_adamw(float* p, float* m, float* v, const vits_adamw_entry* host_entrie
                double beta1, double beta2, double eps, double weight_decay, float* partials, size_t partials_len, void* stream);
 int vits_gradnorm_final(const float* partials, size_t n, float* norm_out, float* state, int bump_step, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Kernels around the alignment step (csrc/align.hip).
+ *
+ * vits_neg_cent — replaces models.py:470-477 (s_p_sq_r, neg_cent1..4 and their sum: two matmuls, two reductions and
+ *   six element-wise ops over [b, t_t, t_s] tensors) by one fp32 matrix-core product [z^2 | z] x [-0.5 r | m r]^T + bias:
+ *     z    [b][t_t][c] channels-last latent frames (row pitch ldz elements), z_dtype VITS_DT_F32 | VITS_DT_BF16;
+ *     m, logs [b][t_s][c] prior statistics (row pitch lds elements; they may be the two halves of one [b][t_s][2c]
+ *          tensor), s_dtype likewise;
+ *     nc   [b][t_t][t_s] float32, fully written — the `neg_cent` operand of vits_mas_f32.
+ * vits_slice_segments — replaces commons.slice_segments (commons.py:48-57; used by rand_slice_segments :60-67 and
+ *   finetune_speaker_v2.py:190,203) and, with backward = 1, its gradient:
+ *     time_inner = 0: x [b][t][d] channels-last -> y [b][seg][d];  time_inner = 1: x [b][d][t] -> y [b][d][seg];
+ *     item i starts at ids[i] * ids_mul (int64 ids as torch makes them); rows outside [0, t) read as 0;
+ *     backward = 1: x is the gradient of the slice ([b][seg][d] / [b][d][seg]) and y the full-size gradient, every
+ *     element written (zeros outside the segment).  elem_bytes 2 | 4 (values are moved, not interpreted).
+ * vits_generate_path — replaces commons.generate_path (commons.py:131-146):
+ *     duration float32 [b][t_x], mask float32 [b][t_y][t_x] -> path float32 [b][t_y][t_x].
+ * ------------------------------------------------------------------------------------------ */
+int vits_neg_cent(int z_dtype, const void* z, long ldz, int s_dtype, const void* m, const void* logs, long lds, float* nc,
+                  int b, int t_t, int t_s, int c, void* stream);
+int vits_slice_segments(int elem_bytes, int time_inner, const void* x, const int64_t* ids, long ids_mul, void* y, int b, int d,
+                        int t, int seg, int backward, void* stream);
+int vits_generate_path(const float* duration, const float* mask, float* path, int b, int t_y, int t_x, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,6 +61,9 @@ SIGNATURES = {
     "vits_adamw_blocks": (c_size_t, [c_void_p, c_int]),
     "vits_adamw": (c_int, [c_void_p] * 4 + [c_int, c_void_p] + [ctypes.c_double] * 4 + [c_void_p, c_size_t, c_void_p]),
     "vits_gradnorm_final": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_int, c_void_p]),
+    "vits_neg_cent": (c_int, [c_int, c_void_p, ctypes.c_long, c_int, c_void_p, c_void_p, ctypes.c_long, c_void_p] + [c_int] * 4 + [c_void_p]),
+    "vits_slice_segments": (c_int, [c_int, c_int, c_void_p, c_void_p, ctypes.c_long, c_void_p] + [c_int] * 5 + [c_void_p]),
+    "vits_generate_path": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
 }
 
 class ConvDesc(ctypes.Structure):

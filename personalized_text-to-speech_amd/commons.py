@@ -34,9 +34,14 @@ def sequence_mask(length, max_length=None):
     return x.unsqueeze(0) < length.unsqueeze(1)
 
 
-def slice_segments(x, ids_str, segment_size=4):
-    """x [b, d, t] -> [b, d, segment_size] starting at ids_str[b] (reference commons.py:48-57,
-    there a Python loop over the batch; here one gather, no host sync)."""
+def slice_segments(x, ids_str, segment_size=4, ids_scale=1):
+    """x [b, d, t] -> [b, d, segment_size] starting at ids_str[b] * ids_scale (reference commons.py:48-57, there a Python loop
+    over the batch with a host sync per item).  GPU tensors: one HIP launch (kernels.slice_segments, differentiable);
+    host tensors (data pipeline, unit tests): one gather."""
+    if x.is_cuda:
+        from . import kernels
+        return kernels.slice_segments(x, ids_str, segment_size, ids_scale)
+    ids_str = ids_str * ids_scale
     idx = ids_str.view(-1, 1, 1) + torch.arange(segment_size, device=x.device).view(1, 1, -1)
     idx = idx.expand(-1, x.size(1), -1)
     return torch.gather(x, 2, idx)
@@ -54,6 +59,9 @@ def rand_slice_segments(x, x_lengths=None, segment_size=4):
 
 def generate_path(duration, mask):
     """duration [b,1,t_x], mask [b,1,t_y,t_x] -> hard monotonic path (reference commons.py:131-146)."""
+    if duration.is_cuda:
+        from . import kernels
+        return kernels.generate_path(duration, mask)
     b, _, t_y, t_x = mask.shape
     cum = torch.cumsum(duration, -1).view(b, t_x, 1)
     frame = torch.arange(t_y, dtype=duration.dtype, device=duration.device).view(1, 1, t_y)

@@ -29,6 +29,7 @@ BACKENDS = {
     "feature-matching / KL / duration sums, bias + conditioning column sums": "hip",   # reduce.hip
     "element-wise glue, adversarial loss arithmetic, embedding lookups, mel matmul": "rocm",   # PyTorch-ROCm device ops
     "adamw + gradient L2 norm (flat buffers, multi-tensor)": "hip",   # adamw.hip (optim.FlatAdamW)
+    "neg_cent (alignment scores), slice_segments (+autograd), generate_path": "hip",   # align.hip
 }
 
 
@@ -38,6 +39,82 @@ def maximum_path(neg_cent, mask):
 
 
 # ------------------------------------------------------------------ convolutions
+def neg_cent(z_p, m_p, logs_p):
+    """models.py:470-477 as ONE launch (csrc/align.hip, vits_neg_cent): z_p [b, c, t_t], m_p / logs_p [b, c, t_s] in the
+    reference's layout — here transposed views of channels-last tensors (the prior statistics may be the two halves of one
+    projection output), fp32 or bf16 — -> fp32 [b, t_t, t_s].  No gradient (the reference builds it under no_grad)."""
+    _lib.require_cuda(z_p, m_p, logs_p)
+    dt = {torch.float32: 0, torch.bfloat16: 2}
+    rows = lambda t: t.transpose(1, 2) if t.stride(1) == 1 else t.transpose(1, 2).contiguous()     # -> [b][t][c], unit channel stride
+    z, m, l = rows(z_p.detach()), rows(m_p.detach()), rows(logs_p.detach())
+    if l.dtype != m.dtype:
+        l = l.to(m.dtype)
+    b, t_t, c = z.shape
+    t_s = m.size(1)
+    for t in (z, m, l):
+        if t.stride(0) != t.size(1) * t.stride(1):
+            raise ValueError("neg_cent: items must lie back to back")
+    if m.stride(1) != l.stride(1):
+        m, l = m.contiguous(), l.contiguous()
+    out = torch.empty(b, t_t, t_s, dtype=torch.float32, device=z.device)
+    e0 = _lib.timer.start("vits_neg_cent")
+    rc = _lib.lib().vits_neg_cent(dt[z.dtype], z.data_ptr(), z.stride(1), dt[m.dtype], m.data_ptr(), l.data_ptr(), m.stride(1),
+                                  out.data_ptr(), b, t_t, t_s, c, _lib.stream_ptr())
+    _lib.timer.stop("vits_neg_cent", e0, (4.0 * b * t_t * t_s * c, z.element_size() * b * t_t * c + 2.0 * m.element_size() * b * t_s * c + 4.0 * b * t_t * t_s))
+    _lib.check(rc, "vits_neg_cent")
+    return out
+
+
+class _SliceSegments(torch.autograd.Function):
+    """commons.slice_segments on the GPU (csrc/align.hip): one launch forward, one launch backward (which writes the whole
+    gradient, zeros included)."""
+
+    @staticmethod
+    def forward(ctx, x, ids, seg, mul):
+        # x [b, d, t]: either contiguous (time innermost) or a transposed view of a channels-last [b, t, d] tensor
+        rows = x.stride(1) == 1 and x.transpose(1, 2).is_contiguous() and x.size(1) > 1
+        if not rows and not x.is_contiguous():
+            x = x.contiguous()
+        b, d, t = x.shape
+        ids = ids.to(torch.int64).contiguous()
+        y = torch.empty((b, seg, d) if rows else (b, d, seg), dtype=x.dtype, device=x.device)
+        rc = _lib.lib().vits_slice_segments(x.element_size(), 0 if rows else 1, x.data_ptr(), ids.data_ptr(), mul, y.data_ptr(), b, d, t, seg, 0,
+                                            _lib.stream_ptr())
+        _lib.check(rc, "vits_slice_segments")
+        ctx.save_for_backward(ids)
+        ctx.geom = (rows, b, d, t, seg, mul)
+        return y.transpose(1, 2) if rows else y
+
+    @staticmethod
+    def backward(ctx, dy):
+        rows, b, d, t, seg, mul = ctx.geom
+        ids, = ctx.saved_tensors
+        dy = (dy.transpose(1, 2) if rows else dy).contiguous()
+        dx = torch.empty((b, t, d) if rows else (b, d, t), dtype=dy.dtype, device=dy.device)
+        rc = _lib.lib().vits_slice_segments(dy.element_size(), 0 if rows else 1, dy.data_ptr(), ids.data_ptr(), mul, dx.data_ptr(), b, d, t, seg, 1,
+                                            _lib.stream_ptr())
+        _lib.check(rc, "vits_slice_segments")
+        return (dx.transpose(1, 2) if rows else dx), None, None, None
+
+
+def slice_segments(x, ids_str, segment_size, ids_scale=1):
+    _lib.require_cuda(x, ids_str)
+    if x.element_size() not in (2, 4):
+        raise ValueError("slice_segments: 2- or 4-byte elements")
+    return _SliceSegments.apply(x, ids_str, int(segment_size), int(ids_scale))
+
+
+def generate_path(duration, mask):
+    """commons.generate_path on the GPU (csrc/align.hip): duration [b, 1, t_x], mask [b, 1, t_y, t_x] -> path of mask's shape."""
+    _lib.require_cuda(duration, mask)
+    b, _, t_y, t_x = mask.shape
+    d = duration.detach().reshape(b, t_x).float().contiguous()
+    m = mask.detach().reshape(b, t_y, t_x).float().contiguous()
+    path = torch.empty_like(m)
+    _lib.check(_lib.lib().vits_generate_path(d.data_ptr(), m.data_ptr(), path.data_ptr(), b, t_y, t_x, _lib.stream_ptr()), "vits_generate_path")
+    return path.view(b, 1, t_y, t_x).to(mask.dtype)
+
+
 def weight_norm(v, g):
     """w = g * v / ||v||_2, norm over every dim but 0 (legacy torch.nn.utils.weight_norm, dim=0;
     reference models.py:254, modules.py:128,135,145,191-206).  For ConvTranspose1d weights

@@ -472,18 +472,10 @@ class SynthesizerTrn(nn.Module):
 
     @staticmethod
     def neg_cent(z_p, m_p, logs_p):
-        """Negative cross-entropy of every (frame, token) pair (models.py:470-477), fp32 — also inside an autocast region:
-        this tensor feeds the discrete alignment DP, and bf16 products (errors ~0.5 on values ~100) change paths."""
-        if z_p.is_cuda and torch.is_autocast_enabled():
-            with torch.autocast("cuda", enabled=False):
-                return SynthesizerTrn.neg_cent(z_p, m_p, logs_p)
-        z_p, m_p, logs_p = z_p.float(), m_p.float(), logs_p.float()
-        s_p_sq_r = torch.exp(-2 * logs_p)                                              # [b, d, t_s]
-        neg_cent1 = torch.sum(-0.5 * commons.LOG_2PI - logs_p, [1], keepdim=True)      # [b, 1, t_s]
-        neg_cent2 = torch.matmul(-0.5 * (z_p ** 2).transpose(1, 2), s_p_sq_r)          # [b, t_t, t_s]
-        neg_cent3 = torch.matmul(z_p.transpose(1, 2), (m_p * s_p_sq_r))                # [b, t_t, t_s]
-        neg_cent4 = torch.sum(-0.5 * (m_p ** 2) * s_p_sq_r, [1], keepdim=True)         # [b, 1, t_s]
-        return neg_cent1 + neg_cent2 + neg_cent3 + neg_cent4
+        """Negative cross-entropy of every (frame, token) pair (models.py:470-477) as one fp32 matrix-core launch
+        (csrc/align.hip) — fp32 also inside an autocast region: this tensor feeds the discrete alignment DP, and bf16
+        products (errors ~0.5 on values ~100) change paths."""
+        return K.neg_cent(z_p, m_p, logs_p)
 
     @staticmethod
     def _arena_specs(net):

@@ -86,7 +86,7 @@ class FineTuner:
             y_hat_mel = mel_spectrogram_torch(y_hat.squeeze(1), hps.data.filter_length, hps.data.n_mel_channels,
                                               hps.data.sampling_rate, hps.data.hop_length, hps.data.win_length,
                                               hps.data.mel_fmin, hps.data.mel_fmax)
-            y = commons.slice_segments(y, ids_slice * hps.data.hop_length, hps.train.segment_size)
+            y = commons.slice_segments(y, ids_slice, hps.train.segment_size, ids_scale=hps.data.hop_length)
 
             # ---- discriminator step (finetune_speaker_v2.py:205-214)
             y_d_hat_r, y_d_hat_g, _, _ = self.net_d(y, y_hat.detach())
