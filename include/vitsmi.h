@@ -396,6 +396,29 @@ int vits_adamw(float* p, float* m, float* v, const vits_adamw_entry* host_entrie
 int vits_gradnorm_final(const float* partials, size_t n, float* norm_out, float* state, int bump_step, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Least-squares GAN losses over the logits of all discriminators in one pass (csrc/reduce.hip).
+ *
+ * Replaces: losses.discriminator_loss (losses.py:18-32) and losses.generator_loss (losses.py:35-43): per discriminator
+ *           `torch.mean((1 - dr) ** 2)`, `torch.mean(dg ** 2)` resp. `torch.mean((1 - dg) ** 2)`, their sum, and the autograd
+ *           of those ~10 element-wise ops per discriminator.
+ *   item d : y8 [J][R][8] logits of discriminator d as vits_disc_post_fwd leaves them (channel 0 live), items j < J/2 real,
+ *            the rest generated; dy8 same shape (backward only): every element is written (zeros where no term applies);
+ *   mode 0 : out[0] = sum_d ( mean_real (1 - y)^2 + mean_generated y^2 );  mode 1: out[0] = sum_d mean_generated (1 - y)^2;
+ *            out[1 + 2d], out[2 + 2d] = the real / generated term of discriminator d (r_losses / g_losses / gen_losses);
+ *            total (optional) receives a second copy of out[0];
+ *   g      : device float, the gradient of out[0];  host_items is a HOST array (passed on by value), n_items <= 8.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const void* y8;
+  void* dy8;
+  int J, R;
+} vits_lsgan_item;
+size_t vits_lsgan_workspace(int n_items);
+int vits_lsgan_loss(int dtype, const vits_lsgan_item* host_items, int n_items, int mode, float* out, float* total,
+                    void* workspace, size_t workspace_bytes, void* stream);
+int vits_lsgan_loss_bwd(int dtype, const vits_lsgan_item* host_items, int n_items, int mode, const float* g, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Kernels around the alignment step (csrc/align.hip).
  *
  * vits_neg_cent — replaces models.py:470-477 (s_p_sq_r, neg_cent1..4 and their sum: two matmuls, two reductions and

@@ -61,6 +61,9 @@ SIGNATURES = {
     "vits_adamw_blocks": (c_size_t, [c_void_p, c_int]),
     "vits_adamw": (c_int, [c_void_p] * 4 + [c_int, c_void_p] + [ctypes.c_double] * 4 + [c_void_p, c_size_t, c_void_p]),
     "vits_gradnorm_final": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_int, c_void_p]),
+    "vits_lsgan_workspace": (c_size_t, [c_int]),
+    "vits_lsgan_loss": (c_int, [c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "vits_lsgan_loss_bwd": (c_int, [c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "vits_neg_cent": (c_int, [c_int, c_void_p, ctypes.c_long, c_int, c_void_p, c_void_p, ctypes.c_long, c_void_p] + [c_int] * 4 + [c_void_p]),
     "vits_slice_segments": (c_int, [c_int, c_int, c_void_p, c_void_p, ctypes.c_long, c_void_p] + [c_int] * 5 + [c_void_p]),
     "vits_generate_path": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
@@ -79,6 +82,11 @@ class PrepEntry(ctypes.Structure):
     """vits_prep_entry of include/vitsmi.h"""
     _fields_ = [("v", c_void_p), ("g", c_void_p), ("off", ctypes.c_int64), ("off_dv", ctypes.c_int64), ("off_dg", ctypes.c_int64)] + \
                [(n, ctypes.c_int32) for n in ("layout", "c_out", "c_in", "k", "c_out_p", "c_in_p", "row_lo", "n_rows", "row0", "groups")]
+
+
+class LsganItem(ctypes.Structure):
+    """vits_lsgan_item of include/vitsmi.h"""
+    _fields_ = [("y8", c_void_p), ("dy8", c_void_p), ("J", c_int), ("R", c_int)]
 
 
 class AdamwEntry(ctypes.Structure):

@@ -201,6 +201,119 @@ int pick_splits(size_t seg_len, int n_seg) {
 
 }  // namespace
 
+namespace {
+
+// ---- least-squares GAN losses over the logits of all discriminators (losses.py:18-43) -----------------------------------
+// item d: y8 [J][R][8], channel 0 live, items j < J/2 real, the rest generated.
+//   mode 0 (discriminator_loss): sum_d mean_real (1 - y)^2 + mean_gen y^2       mode 1 (generator_loss): sum_d mean_gen (1 - y)^2
+constexpr int kLsganMax = 8, kLsganSplits = 16;
+struct LsganTable { const void* y8[kLsganMax]; void* dy8[kLsganMax]; int J[kLsganMax], R[kLsganMax]; int count; };
+
+// grid (kLsganSplits, 2 halves, items): partial[(d*2 + half) * kLsganSplits + split]
+template <typename T>
+__global__ __launch_bounds__(kThreads) void lsgan_partial_kernel(LsganTable tab, int mode, float* __restrict__ partial) {
+  __shared__ float red[4];
+  const int d = blockIdx.z, half = blockIdx.y;
+  const size_t n = (size_t)(tab.J[d] / 2) * tab.R[d];
+  const T* y = static_cast<const T*>(tab.y8[d]) + (size_t)half * n * 8;
+  float acc = 0.f;
+  if (!(mode == 1 && half == 0)) {
+    const bool one_minus = (mode == 1) || half == 0;
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (size_t)kLsganSplits * kThreads) {
+      const float v = ld<T>(y, i * 8);
+      const float u = one_minus ? 1.0f - v : v;
+      acc += u * u;
+    }
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) partial[((size_t)d * 2 + half) * kLsganSplits + blockIdx.x] = acc;
+}
+
+// out[0] = total, out[1 + 2d + half] = the term of discriminator d (mean over its half); one wave, fixed order
+__global__ __launch_bounds__(64) void lsgan_final_kernel(LsganTable tab, const float* __restrict__ partial, float* __restrict__ out,
+                                                         float* __restrict__ total_out) {
+  if (threadIdx.x != 0) return;
+  float total = 0.f;
+  for (int d = 0; d < tab.count; ++d)
+    for (int half = 0; half < 2; ++half) {
+      float s = 0.f;
+      for (int k = 0; k < kLsganSplits; ++k) s += partial[((size_t)d * 2 + half) * kLsganSplits + k];
+      s /= (float)((size_t)(tab.J[d] / 2) * tab.R[d]);
+      out[1 + 2 * d + half] = s;
+      total += s;
+    }
+  out[0] = total;
+  if (total_out) *total_out = total;
+}
+
+// dy8[j][r][0] = g * 2 (y - 1) / n  (or 2 y / n), channels 1..7 and the halves without a term = 0; every element written
+template <typename T>
+__global__ __launch_bounds__(kThreads) void lsgan_bwd_kernel(LsganTable tab, int mode, const float* __restrict__ g) {
+  const int d = blockIdx.y;
+  const size_t n = (size_t)(tab.J[d] / 2) * tab.R[d];
+  const T* y = static_cast<const T*>(tab.y8[d]);
+  T* dy = static_cast<T*>(tab.dy8[d]);
+  const float scale = 2.0f * g[0] / (float)n;
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < 2 * n; i += (size_t)gridDim.x * kThreads) {
+    const int half = i >= n;
+    float v = 0.f;
+    if (!(mode == 1 && half == 0)) {
+      const float yv = ld<T>(y, i * 8);
+      v = scale * (((mode == 1) || half == 0) ? yv - 1.0f : yv);
+    }
+    T row[8];
+    row[0] = (T)v;
+#pragma unroll
+    for (int c = 1; c < 8; ++c) row[c] = (T)0.f;
+    T* dst = dy + i * 8;
+    if constexpr (sizeof(T) == 2) *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(row);
+    else { *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(row); *reinterpret_cast<uint4*>(dst + 4) = *reinterpret_cast<const uint4*>(row + 4); }
+  }
+}
+
+int lsgan_table(const vits_lsgan_item* items, int n_items, LsganTable& tab, bool need_dy) {
+  if (!items || n_items <= 0 || n_items > kLsganMax) return VITS_E_BADARG;
+  tab.count = n_items;
+  for (int i = 0; i < n_items; ++i) {
+    if (!items[i].y8 || items[i].J <= 0 || items[i].J % 2 != 0 || items[i].R <= 0 || (need_dy && !items[i].dy8)) return VITS_E_BADARG;
+    tab.y8[i] = items[i].y8; tab.dy8[i] = items[i].dy8; tab.J[i] = items[i].J; tab.R[i] = items[i].R;
+  }
+  return VITS_OK;
+}
+
+}  // namespace
+
+extern "C" size_t vits_lsgan_workspace(int n_items) { return (size_t)n_items * 2 * kLsganSplits * sizeof(float); }
+
+extern "C" int vits_lsgan_loss(int dtype, const vits_lsgan_item* host_items, int n_items, int mode, float* out, float* total,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+  LsganTable tab;
+  int rc = lsgan_table(host_items, n_items, tab, false);
+  if (rc != VITS_OK) return rc;
+  if (!out || !workspace || workspace_bytes < vits_lsgan_workspace(n_items) || (mode != 0 && mode != 1)) return VITS_E_BADARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float* partial = static_cast<float*>(workspace);
+  const dim3 grid(kLsganSplits, 2, n_items);
+  if (dtype == VITS_DT_BF16) hipLaunchKernelGGL(lsgan_partial_kernel<__bf16>, grid, dim3(kThreads), 0, s, tab, mode, partial);
+  else if (dtype == VITS_DT_F32) hipLaunchKernelGGL(lsgan_partial_kernel<float>, grid, dim3(kThreads), 0, s, tab, mode, partial);
+  else return VITS_E_UNSUPPORTED;
+  hipLaunchKernelGGL(lsgan_final_kernel, dim3(1), dim3(64), 0, s, tab, partial, out, total);
+  return vits::check_launch("vits_lsgan_loss");
+}
+
+extern "C" int vits_lsgan_loss_bwd(int dtype, const vits_lsgan_item* host_items, int n_items, int mode, const float* g, void* stream) {
+  LsganTable tab;
+  int rc = lsgan_table(host_items, n_items, tab, true);
+  if (rc != VITS_OK) return rc;
+  if (!g || (mode != 0 && mode != 1)) return VITS_E_BADARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid(64, n_items);
+  if (dtype == VITS_DT_BF16) hipLaunchKernelGGL(lsgan_bwd_kernel<__bf16>, grid, dim3(kThreads), 0, s, tab, mode, g);
+  else if (dtype == VITS_DT_F32) hipLaunchKernelGGL(lsgan_bwd_kernel<float>, grid, dim3(kThreads), 0, s, tab, mode, g);
+  else return VITS_E_UNSUPPORTED;
+  return vits::check_launch("vits_lsgan_loss_bwd");
+}
+
 extern "C" size_t vits_reduce_workspace(int n_seg) { return (size_t)n_seg * kMaxSplits * sizeof(float); }
 
 extern "C" int vits_absdiff_sum(int dtype, const void* a, const void* b, size_t n, float scale, float* out, int accumulate,

@@ -16,7 +16,19 @@ def feature_loss(fmap_r, fmap_g):
     return loss * 2
 
 
+def _fused_logits(*lists):
+    y8 = getattr(lists[0], "y8", None)
+    if y8 is not None and all(getattr(l, "y8", None) is y8 for l in lists) and y8[0].is_cuda and len(y8) <= 8:
+        return y8
+    return None
+
+
 def discriminator_loss(disc_real_outputs, disc_generated_outputs):
+    y8 = _fused_logits(disc_real_outputs, disc_generated_outputs)
+    if y8 is not None:                         # both lists come from one MultiPeriodDiscriminator call: one fused pass
+        from . import reduce
+        loss, terms = reduce.lsgan(y8, 0)
+        return loss, [terms[1 + 2 * d] for d in range(len(y8))], [terms[2 + 2 * d] for d in range(len(y8))]
     loss = 0
     r_losses, g_losses = [], []
     for dr, dg in zip(disc_real_outputs, disc_generated_outputs):
@@ -29,6 +41,11 @@ def discriminator_loss(disc_real_outputs, disc_generated_outputs):
 
 
 def generator_loss(disc_outputs):
+    y8 = _fused_logits(disc_outputs)
+    if y8 is not None:
+        from . import reduce
+        loss, terms = reduce.lsgan(y8, 1)
+        return loss, [terms[2 + 2 * d] for d in range(len(y8))]
     loss = 0
     gen_losses = []
     for dg in disc_outputs:

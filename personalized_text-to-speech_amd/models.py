@@ -413,14 +413,15 @@ class MultiPeriodDiscriminator(nn.Module):
         kernel sees twice the rows), and all six discriminators are ONE autograd node (disc_cl.DiscFn).  When the
         discriminator is frozen (generator step) only the generated half needs a backward: n_lo = b."""
         from . import disc_cl, weight_arena
-        from .reduce import FmapLists
+        from .reduce import FmapLists, LogitLists
         b = y.size(0)
         yy = torch.cat([y, y_hat], 0)
         frozen = not any(p.requires_grad for p in self.parameters())
         with weight_arena.scope(self, MultiPeriodDiscriminator._arena_specs):
             res = disc_cl.run(list(self.discriminators), yy[:, 0, :].float(), n_lo=b if frozen else 0)
         outs = [_disc_outputs(d.period, 2 * b, y8, hs) for d, (y8, hs) in zip(self.discriminators, res)]
-        y_d_rs, y_d_gs = [], []
+        y_d_rs, y_d_gs = LogitLists(), LogitLists()
+        y_d_rs.y8 = y_d_gs.y8 = [y8 for y8, _ in res]           # fused least-squares losses read the logits where they lie
         fmap_rs, fmap_gs = FmapLists(), FmapLists()
         cl, den = [], []
         for out, fmap in outs:

@@ -101,6 +101,56 @@ def feature_l1(hs, dens=None):
     return _FeatureL1.apply(dens, *hs)
 
 
+class _Lsgan(torch.autograd.Function):
+    """losses.discriminator_loss / generator_loss over the logit tensors of all discriminators: two launches forward
+    (partials, fixed-order final), one backward (csrc/reduce.hip, vits_lsgan_loss[_bwd])."""
+
+    @staticmethod
+    def forward(ctx, mode, *y8s):
+        import ctypes
+        L = _lib.lib()
+        ys = [y.detach() for y in y8s]
+        assert all(y.is_contiguous() and y.dim() == 3 and y.size(2) == 8 and y.dtype == ys[0].dtype for y in ys)
+        _lib.require_cuda(*ys)
+        items = (_lib.LsganItem * len(ys))()
+        for it, y in zip(items, ys):
+            it.y8, it.dy8, it.J, it.R = y.data_ptr(), None, y.size(0), y.size(1)
+        out = torch.empty(1 + 2 * len(ys), device=ys[0].device, dtype=torch.float32)
+        total = torch.empty((), device=ys[0].device, dtype=torch.float32)
+        nbytes = L.vits_lsgan_workspace(len(ys))
+        ws = K.workspace(nbytes, ys[0].device)
+        _lib.check(L.vits_lsgan_loss(_DT[ys[0].dtype], ctypes.addressof(items), len(ys), mode, out.data_ptr(), total.data_ptr(), ws.data_ptr(),
+                                     nbytes, _lib.stream_ptr()), "vits_lsgan_loss")
+        ctx.save_for_backward(*ys)
+        ctx.mode = mode
+        ctx.mark_non_differentiable(out)                     # only the total (returned separately) carries a gradient
+        return total, out
+
+    @staticmethod
+    def backward(ctx, g, _):
+        import ctypes
+        ys = ctx.saved_tensors
+        dys = [torch.empty_like(y) for y in ys]
+        items = (_lib.LsganItem * len(ys))()
+        for it, y, dy in zip(items, ys, dys):
+            it.y8, it.dy8, it.J, it.R = y.data_ptr(), dy.data_ptr(), y.size(0), y.size(1)
+        gf = g.detach().float().contiguous().view(1)
+        _lib.check(_lib.lib().vits_lsgan_loss_bwd(_DT[ys[0].dtype], ctypes.addressof(items), len(ys), ctx.mode, gf.data_ptr(), _lib.stream_ptr()),
+                   "vits_lsgan_loss_bwd")
+        return (None, *dys)
+
+
+def lsgan(y8s, mode):
+    """-> (total loss with gradient, per-term values [1 + 2 n]: [total, real_0, generated_0, real_1, ...] detached)"""
+    return _Lsgan.apply(int(mode), *y8s)
+
+
+class LogitLists(list):
+    """The per-discriminator logit lists MultiPeriodDiscriminator returns (reference layout [b, t'] views), carrying the
+    contiguous [J][R][8] tensors they are views of (`y8`: real items first, generated second) for the fused GAN losses."""
+    y8 = None
+
+
 class FmapLists(list):
     """The list of per-discriminator feature-map lists MultiPeriodDiscriminator returns (reference layout views), carrying
     the channels-last tensors they are views of (`cl`: real items first, generated items second) for the fused loss."""

@@ -90,3 +90,54 @@ def test_colsum(pkg, dtype):
         a, b = pkg.kernels.colsum(x, per_item=True), x.double().sum(1)
         assert a.shape == b.shape and torch.allclose(a.double(), b, rtol=1e-4, atol=1e-2)
         assert torch.equal(pkg.kernels.colsum(x), pkg.kernels.colsum(x))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_lsgan_losses_match_reference_formulas(pkg, dtype):
+    """reduce.lsgan (vits_lsgan_loss[_bwd]) against losses.py:18-43 written out with torch ops, values and gradients; and
+    losses.discriminator_loss / generator_loss pick the fused pass for lists that carry their [J][R][8] logits."""
+    torch.manual_seed(12)
+    red, losses = pkg.reduce, pkg.losses
+    shapes = [(32, 8192), (64, 46), (96, 31), (160, 19), (224, 14), (352, 9), (2, 1)]
+    y8s = []
+    for J, R in shapes:
+        y = torch.zeros(J, R, 8, device="cuda:0")
+        y[..., 0] = torch.randn(J, R, device="cuda:0") * 0.7 + 0.3
+        y8s.append(y.to(dtype).requires_grad_(True))
+    for mode in (0, 1):
+        refs = [y.detach().clone().requires_grad_(True) for y in y8s]
+        want, terms = 0, []
+        for y in refs:
+            v = y[..., 0].float()
+            h = v.size(0) // 2
+            if mode == 0:
+                r, g = torch.mean((1 - v[:h]) ** 2), torch.mean(v[h:] ** 2)
+            else:
+                r, g = torch.zeros((), device=v.device), torch.mean((1 - v[h:]) ** 2)
+            want = want + r + g
+            terms += [r, g]
+        (want * 1.7).backward()
+        total, out = red.lsgan(y8s, mode)
+        for y in y8s:
+            y.grad = None
+        (total * 1.7).backward()
+        assert abs(float(total) - float(want)) <= 2e-6 * abs(float(want)) and float(out[0]) == float(total)
+        for i, t in enumerate(terms):
+            assert abs(float(out[1 + i]) - float(t)) <= 2e-6 * max(abs(float(t)), 1e-6), (mode, i)
+        for y, r in zip(y8s, refs):
+            tol = 1e-6 if dtype == torch.float32 else 8e-3
+            assert y.grad.shape == y.shape and float((y.grad.float() - r.grad.float()).abs().max()) <= tol * float(r.grad.float().abs().max()), mode
+            assert float(y.grad[..., 1:].abs().max()) == 0.0
+        assert torch.equal(red.lsgan(y8s, mode)[1], out)                       # fixed-order sums
+    # the public functions route lists that carry `y8`
+    rs, gs = red.LogitLists(), red.LogitLists()
+    for y in y8s[:6]:
+        flat = y[..., 0].reshape(y.size(0), -1)
+        rs.append(flat[: y.size(0) // 2]); gs.append(flat[y.size(0) // 2:])
+    plain = losses.discriminator_loss(list(rs), list(gs))
+    rs.y8 = gs.y8 = y8s[:6]
+    fused = losses.discriminator_loss(rs, gs)
+    assert abs(float(fused[0]) - float(plain[0])) <= 1e-5 * abs(float(plain[0])) and len(fused[1]) == len(fused[2]) == 6
+    assert all(abs(float(a) - float(b)) <= 1e-5 * abs(float(b)) for a, b in zip(fused[1] + fused[2], plain[1] + plain[2]))
+    gl_f, gl_p = losses.generator_loss(gs), losses.generator_loss(list(gs))
+    assert abs(float(gl_f[0]) - float(gl_p[0])) <= 1e-5 * abs(float(gl_p[0])) and len(gl_f[1]) == 6
