@@ -108,6 +108,8 @@ int vits_mas_f32(const float* neg_cent, void* path, int path_dtype,
 
 #define VITS_CONV_FLAT      256 /* force the flat-row kernel (rows = (item, time) pairs; chosen automatically for strided,
                                    divided and short-sequence launches) */
+#define VITS_CONV_BIG_TILES 512 /* vits_conv1d_cl_wgrad only: take the 128 x 128-tile kernel wherever it can run (by default only
+                                   where it is the faster one: stride 1, >= 512 channels on both sides) */
 #define VITS_CONV_OUT_LRELU 128 /* y = leaky_relu(., out_slope) applied after residual/scale (discriminator feature maps) */
 
 /* All sizes in elements.  Zero in ldx / ldy / ldy2 / stride means "dense" / 1. */

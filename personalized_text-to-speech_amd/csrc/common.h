@@ -24,6 +24,11 @@ int conv1d_flat_dispatch(const vits_conv_desc& d, int t_out, hipStream_t s);
 // csrc/conv1d_ring.hip: LDS-DMA ring variant (bf16, c_in % 64 == 0, k >= 2); VITS_E_UNSUPPORTED = take another kernel
 int conv1d_ring_dispatch(const vits_conv_desc& d, int t_out, hipStream_t s);
 
+// csrc/conv1d_wgrad_ring.hip: large-tile, deep-prefetch weight-gradient kernel (bf16); plan.TC == 0: not eligible
+struct WgradRingPlan { int TC, TK, KT, XR, S; };
+WgradRingPlan wgrad_ring_plan(const vits_wgrad_desc& d, int t_out, int s_max);
+int wgrad_ring_launch(const vits_wgrad_desc& d, int t_out, const WgradRingPlan& p, float* partial, float* partial_db, size_t slab, hipStream_t s);
+
 // Raise a kernel's dynamic-LDS limit to the hardware maximum (a per-device function attribute): once per device and
 // kernel, to a FIXED value — a per-launch value would be whatever the LAST call set by the time a captured graph replays.
 inline hipError_t ensure_max_dynamic_lds(const void* kern, int reserve_static = 0) {

@@ -506,7 +506,10 @@ static int wgrad_impl(const vits_wgrad_desc* desc, void* stream, vits_wgrad_pend
     if (ig > og || CT % og != 0 || CT % ((CT / og) * ig) != 0) return VITS_E_UNSUPPORTED;
   }
   const bool flat = d.groups > 1 || d.stride > 1 || (d.flags & VITS_CONV_FLAT) != 0 || (auto_flat && t_out <= 80 && d.b >= 8);
-  const int S = pick_splits(d.b, t_out, c_in_eff, d.c_out, d.k, flat);
+  int S = pick_splits(d.b, t_out, c_in_eff, d.c_out, d.k, flat);
+  // large-tile deep-prefetch kernel (csrc/conv1d_wgrad_ring.hip) where it applies: never more splits than the bound above
+  const vits::WgradRingPlan ring = vits::wgrad_ring_plan(d, t_out, S);
+  if (ring.TC) S = ring.S;
   const size_t n = (size_t)d.k * d.c_out * (d.groups > 1 ? d.c_in / d.groups : d.c_in), nb = d.dbias ? (size_t)d.c_out : 0;   // multiples of 4
   const bool accumulate = (d.flags & VITS_CONV_ACCUM) != 0;
   const bool direct = (S == 1) && !accumulate;           // a single split writes dw / db itself: no second launch
@@ -522,7 +525,9 @@ static int wgrad_impl(const vits_wgrad_desc* desc, void* stream, vits_wgrad_pend
               d.dbias ? (direct ? d.dbias : ws + n) : nullptr, direct ? 0 : n + nb};
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc;
-  if (d.dtype == VITS_DT_BF16) {
+  if (ring.TC) {
+    rc = vits::wgrad_ring_launch(d, t_out, ring, a.partial, a.partial_db, a.slab, s);
+  } else if (d.dtype == VITS_DT_BF16) {
     if (d.c_in % 8 != 0 || d.c_out % 8 != 0 || d.ldx % 8 != 0 || d.lddy % 8 != 0) return VITS_E_UNSUPPORTED;
     rc = dispatch_k<__bf16>(a, s, flat);
   } else if (d.dtype == VITS_DT_F32) {

@@ -266,6 +266,7 @@ def stft_magnitude(y, n_fft, hop, win, window):
 # ================================================================================================
 CONV_MASK_IN, CONV_MASK_OUT, CONV_TANH, CONV_ACCUM, CONV_RES_AFTER, CONV_GATE, CONV_GATE_BWD, CONV_OUT_LRELU = 1, 2, 4, 8, 16, 32, 64, 128
 CONV_FLAT = 256
+CONV_BIG_TILES = 512
 _DT = {torch.float32: 0, torch.bfloat16: 2}
 
 

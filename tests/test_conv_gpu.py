@@ -271,7 +271,7 @@ def test_wgrad_fused_reduction_is_bitwise_the_two_launch_result(pkg):
     K = pkg.kernels
     torch.manual_seed(12)
     for (b, t, ci, co, kk, st, pd, dt) in [(16, 500, 192, 384, 5, 1, 2, torch.bfloat16), (16, 500, 192, 192, 1, 1, 0, torch.bfloat16),
-                                           (64, 51, 1024, 1024, 5, 1, 2, torch.bfloat16), (4, 300, 64, 96, 3, 1, 1, torch.float32),
+                                           (64, 51, 256, 320, 5, 1, 2, torch.bfloat16), (4, 300, 64, 96, 3, 1, 1, torch.float32),      # (>= 512 channels: another kernel)
                                            (16, 2048, 32, 32, 7, 1, 3, torch.bfloat16)]:
         x = torch.randn(b, t, ci, device=DEV).to(dt)
         dy = torch.randn(b, (t + 2 * pd - kk) // st + 1, co, device=DEV).to(dt)
@@ -338,3 +338,33 @@ def test_ring_kernel_matches_emulation(pkg):
             kw = dict(kw, pad=kk - 1 - pd, in_div=st, t_out=t_x)
             ya, yb = K.conv1d_cl_raw(dy, w, **kw), cl_emul.conv1d_cl_raw(dy, w, **kw)
             assert ya.shape == yb.shape and rel(ya, yb) < tol, ("in_div", b, t_dy, ci, co, kk, st, sorted(kw))
+
+
+def test_large_tile_wgrad_kernel_matches_emulation(pkg):
+    """csrc/conv1d_wgrad_ring.hip (bf16, >= 64 channels, k >= 2, >= 1024 flat rows, no masks): the discriminator shapes (many
+    short items, stride 3 / 1, 128-1024 channels), the decoder shapes (long items, dilations 1/3/5, fused input leaky-relu),
+    partial channel tiles, a last stage that is mostly empty, accumulate mode and the bias gradient."""
+    import cl_emul
+    K = pkg.kernels
+    torch.manual_seed(21)
+    dtype, tol = torch.bfloat16, 1.5e-2
+    cases = [  # b, t, c_in, c_out, k, stride, dil, pad, in_slope
+        (352, 10, 1024, 1024, 5, 1, 1, 2, 1.0), (96, 34, 1024, 1024, 5, 1, 1, 2, 1.0), (160, 61, 512, 1024, 5, 3, 1, 2, 1.0),
+        (96, 304, 128, 512, 5, 3, 1, 2, 1.0), (16, 2048, 128, 128, 11, 1, 5, 25, 0.1), (16, 256, 256, 256, 7, 1, 3, 9, 0.1),
+        (16, 4096, 64, 64, 11, 1, 1, 5, 0.1), (16, 2048, 128, 128, 3, 1, 1, 1, 0.1), (16, 201, 768, 192, 3, 1, 1, 1, 1.0),
+        (7, 333, 200, 136, 5, 1, 2, 4, 0.1), (3, 1000, 64, 320, 2, 1, 1, 0, 1.0), (40, 33, 256, 128, 4, 2, 1, 1, 1.0),
+    ]
+    for (b, t, ci, co, kk, st, dl, pd, sl) in cases:
+        x = torch.randn(b, t, ci, device=DEV).to(dtype)
+        t_out = (t + 2 * pd - dl * (kk - 1) - 1) // st + 1
+        dy = torch.randn(b, t_out, co, device=DEV).to(dtype)
+        dba, dbb = torch.empty(co, device=DEV), torch.empty(co, device=DEV)
+        big = K.CONV_BIG_TILES                       # (the default rule takes this kernel for the 1024-channel layers only)
+        ga = K.conv1d_cl_wgrad_raw(x, dy, kk, pad=pd, stride=st, dil=dl, in_slope=sl, dbias=dba, flags=big)
+        gb = cl_emul.conv1d_cl_wgrad_raw(x, dy, kk, pad=pd, stride=st, dil=dl, in_slope=sl, dbias=dbb)
+        assert ga.shape == gb.shape and rel(ga, gb) < tol and rel(dba, dbb) < tol, (b, t, ci, co, kk, st, dl, rel(ga, gb), rel(dba, dbb))
+        assert torch.equal(K.conv1d_cl_wgrad_raw(x, dy, kk, pad=pd, stride=st, dil=dl, in_slope=sl, flags=big), ga)      # reproducible
+        acc_a, acc_b = ga.clone(), gb.clone()
+        K.conv1d_cl_wgrad_raw(x, dy, kk, pad=pd, stride=st, dil=dl, in_slope=sl, out=acc_a, flags=K.CONV_ACCUM | big)
+        cl_emul.conv1d_cl_wgrad_raw(x, dy, kk, pad=pd, stride=st, dil=dl, in_slope=sl, out=acc_b, flags=K.CONV_ACCUM)
+        assert rel(acc_a, acc_b) < tol, ("accum", b, t, ci, co, kk)
