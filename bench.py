@@ -161,6 +161,7 @@ def bench_infer(args, P, cfgs, device):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--branches", default=None, help="comma list of side-stream branches (enc_p,dp,mel); default: all")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="C2")
@@ -203,6 +204,8 @@ def main():
     cfg_name, batch_size, t_y_range = cfgs.WORKLOADS[args.workload]
     hps = cfgs.get(cfg_name)
     tuner = tr.FineTuner(hps, device, amp=not args.fp32)
+    if args.branches is not None:
+        tuner.side_branches = frozenset(b for b in args.branches.split(",") if b)
     batch = tr.synthetic_batch(hps, batch_size, t_y_range, device, rank=rank)
 
     def sync():
@@ -211,9 +214,24 @@ def main():
         torch.cuda.synchronize()
 
     use_graph = not args.eager
+    branch_note = None
     if use_graph and world == 1:
-        (tuner.capture_segments if args.segmented else tuner.capture)(batch, warmup=3)
-        tuner.verify_replay()                            # same state -> same result, and agrees with the eager step
+        cap = tuner.capture_segments if args.segmented else tuner.capture
+        cap(batch, warmup=3)
+        try:
+            for _ in range(4):                           # same state -> same result, and agrees with the eager step: four rounds,
+                tuner.verify_replay()                    # because a race between side-stream branches would be intermittent
+        except RuntimeError as e:
+            if not tuner.side_branches:
+                raise
+            # never time a graph that failed verification: recapture the step without side-stream branches (serial) and verify that
+            branch_note = f"side-stream branches {sorted(tuner.side_branches)} switched off after: {str(e)[:160]}"
+            print("bench: " + branch_note, file=sys.stderr)
+            tuner._graph = None
+            tuner.side_branches = frozenset()
+            cap(batch, warmup=1)
+            for _ in range(2):
+                tuner.verify_replay()
     elif use_graph:
         # N > 1: three graphs cut where the ranks exchange gradients, RCCL all-reduce between the replays.  Every stage that
         # issues collectives (warm-up steps, verify_replay's replays and eager step) runs on ALL ranks or on none, and the
@@ -317,8 +335,10 @@ def main():
                     config=dict(workload=f"{args.workload}: {cfg_name}.json, per-rank batch {batch_size}, T_y<= {T_y} frames, "
                                          f"T_x<= {T_x} tokens, segment {hps.train.segment_size} samples, fwd+bwd+AdamW (G and D)",
                                 parallelism=f"dp{world}", execution=("hipGraph replay" if world == 1 and not args.segmented else "three hipGraphs, gradient all-reduce between them") if use_graph else "eager launches",
-                                kernels=P.kernels.BACKENDS, losses=losses),
+                                side_stream_branches=sorted(tuner.side_branches), kernels=P.kernels.BACKENDS, losses=losses),
                     roofline=roof)
+        if branch_note:
+            line["config"]["note"] = branch_note
         if world == 1 and not args.fp32 and not args.no_secondary:
             line["secondary"] = secondary_fp32(tr, hps, device, batch, batch_size)
         if world == 1 and not args.no_cpu_baseline:

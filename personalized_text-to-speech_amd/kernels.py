@@ -371,6 +371,79 @@ def workspace(nbytes, device):
     return buf
 
 
+_side_streams = {}
+
+
+class SideBranch:
+    """Runs a block of launches on a second HIP stream, forked from the current one and joined later with join():
+
+        br = SideBranch(device, inputs...)
+        with br:
+            out = small_latency_bound_subgraph(...)
+        ... independent work on the main stream ...
+        br.join(out)
+
+    PyTorch runs the backward of every op on the stream its forward ran on, so the backward of the block overlaps the
+    backward of the independent work as well; inside a captured hipGraph the two become parallel branches (one fork and one
+    join edge each way, not one per kernel).  Used for the stochastic duration predictor: ~800 launches on [16, 201, 192]
+    tensors that keep a few CUs busy, next to the decoder / discriminators."""
+
+    def __init__(self, device, *inputs, lane=0):
+        """lane: which of the device's side streams to use (branches on different lanes also overlap each other)."""
+        device = torch.device(device)
+        self.main = torch.cuda.current_stream(device)
+        self.side = _side_streams.get((device.index, lane))
+        if self.side is None:
+            self.side = _side_streams[(device.index, lane)] = torch.cuda.Stream(device)
+        self.inputs = [t for t in inputs if torch.is_tensor(t)]
+        self._ctx = None
+
+    def __enter__(self):
+        self.side.wait_stream(self.main)
+        for t in self.inputs:
+            t.record_stream(self.side)
+        self._ctx = torch.cuda.stream(self.side)
+        self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        self._ctx.__exit__(*exc)
+        return False
+
+    def join(self, *outputs):
+        """The main stream waits for the branch.  Returns the outputs wrapped so that, in the backward pass, the gradient that
+        re-enters the branch is first copied into memory that belongs to the SIDE stream (see _HandOff)."""
+        self.main.wait_stream(self.side)
+        res = []
+        for t in outputs:
+            if torch.is_tensor(t):
+                t.record_stream(self.main)
+                if t.requires_grad:
+                    t = _HandOff.apply(t, self.side)
+            res.append(t)
+        return res[0] if len(res) == 1 else tuple(res)
+
+
+class _HandOff(torch.autograd.Function):
+    """Identity whose backward moves the incoming gradient (allocated on the main stream) into a block owned by the side
+    stream before the branch's backward nodes read it: those nodes may still be running long after the main stream has freed
+    and re-used the original block."""
+
+    @staticmethod
+    def forward(ctx, x, side):
+        ctx.side = side
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        main, side = torch.cuda.current_stream(g.device), ctx.side
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            g2 = g.clone()
+        g.record_stream(side)
+        return g2, None
+
+
 class DeferredReductions:
     """Collects the second stages of a group of weight-gradient launches (vits_conv1d_cl_wgrad_deferred) and runs them as ONE
     launch (vits_wgrad_reduce_pending).  Each deferred call gets its own slice of a per-stream slab buffer shared by all

@@ -455,6 +455,7 @@ class SynthesizerTrn(nn.Module):
         self.resblock, self.resblock_kernel_sizes, self.resblock_dilation_sizes = resblock, resblock_kernel_sizes, resblock_dilation_sizes
         self.upsample_rates, self.upsample_initial_channel, self.upsample_kernel_sizes = upsample_rates, upsample_initial_channel, upsample_kernel_sizes
         self.segment_size, self.n_speakers, self.gin_channels, self.use_sdp = segment_size, n_speakers, gin_channels, use_sdp
+        self.side_branches = {"enc_p"}      # training forward: sub-graphs that run as side-stream branches (kernels.SideBranch)
 
         self.enc_p = TextEncoder(n_vocab, inter_channels, hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout)
         self.dec = Generator(inter_channels, resblock, resblock_kernel_sizes, resblock_dilation_sizes, upsample_rates,
@@ -542,10 +543,22 @@ class SynthesizerTrn(nn.Module):
             return self._voice_conversion(y, y_lengths, sid_src, sid_tgt)
 
     def _forward(self, x, x_lengths, y, y_lengths, sid=None):
-        x, m_p, logs_p, x_mask = self.enc_p(x, x_lengths)
+        # The text encoder (~600 launches on [b, t_x, 192] tensors, forward + backward) and the posterior encoder + flow do not
+        # depend on each other until the alignment: two branches (kernels.SideBranch), forward and — because every backward
+        # runs on its forward's stream — backward.
+        enc_branch = K.SideBranch(x.device, x, x_lengths, lane=1) if ("enc_p" in self.side_branches and x.is_cuda) else None
+        if enc_branch is not None:
+            enc_branch.__enter__()
+        try:
+            x, m_p, logs_p, x_mask = self.enc_p(x, x_lengths)
+        finally:
+            if enc_branch is not None:
+                enc_branch.__exit__(None, None, None)
         g = self._speaker(sid)
         z, m_q, logs_q, y_mask = self.enc_q(y, y_lengths, g=g)
         z_p = self.flow(z, y_mask, g=g)
+        if enc_branch is not None:
+            x, m_p, logs_p, x_mask = enc_branch.join(x, m_p, logs_p, x_mask)
 
         with torch.no_grad():
             neg_cent = self.neg_cent(z_p, m_p, logs_p)
@@ -553,13 +566,22 @@ class SynthesizerTrn(nn.Module):
             attn = K.maximum_path(neg_cent, attn_mask.squeeze(1)).unsqueeze(1).detach().to(x.dtype)
 
         w = attn.sum(2)
-        if self.use_sdp:
-            l_length = self.dp(x, x_mask, w, g=g)
-            l_length = l_length / torch.sum(x_mask)
-        else:
-            logw_ = torch.log(w + 1e-6) * x_mask
-            logw = self.dp(x, x_mask, g=g)
-            l_length = commons.sum12((logw - logw_) ** 2) / torch.sum(x_mask)
+        # The duration predictor is ~800 launches on [b, t_x, 192] tensors that occupy a few CUs; nothing below needs its result
+        # before the loss, and its input is detached (models.py:52-53), so it runs as a side branch next to the decoder — forward
+        # here, backward next to the decoder's / discriminators' backward (kernels.SideBranch).
+        branch = K.SideBranch(x.device, x, x_mask, w, g) if ("dp" in self.side_branches and x.is_cuda) else None
+        if branch is not None:
+            branch.__enter__()
+        try:
+            if self.use_sdp:
+                l_length = self.dp(x, x_mask, w, g=g)
+            else:
+                logw_ = torch.log(w + 1e-6) * x_mask
+                logw = self.dp(x, x_mask, g=g)
+                l_length = commons.sum12((logw - logw_) ** 2)
+        finally:
+            if branch is not None:
+                branch.__exit__(None, None, None)
 
         # expand prior
         m_p = torch.matmul(attn.squeeze(1), m_p.transpose(1, 2)).transpose(1, 2)
@@ -567,6 +589,9 @@ class SynthesizerTrn(nn.Module):
 
         z_slice, ids_slice = commons.rand_slice_segments(z, y_lengths, self.segment_size)
         o = self.dec(z_slice, g=g)
+        if branch is not None:
+            l_length = branch.join(l_length)
+        l_length = l_length / torch.sum(x_mask)
         return o, l_length, attn, ids_slice, x_mask, y_mask, (z, z_p, m_p, logs_p, m_q, logs_q)
 
     def _infer(self, x, x_lengths, sid=None, noise_scale=1, length_scale=1, noise_scale_w=1.0, max_len=None, durations=None):

@@ -17,6 +17,7 @@ import torch
 from torch.nn import functional as F
 
 from . import commons, weight_arena
+from . import kernels as K
 from .optim import FlatAdamW
 from .distributed import GradBuckets, broadcast_parameters
 from .losses import discriminator_loss, feature_loss, generator_loss, kl_loss
@@ -45,6 +46,13 @@ class FineTuner:
         self.optim_d = FlatAdamW(self.net_d.parameters(), hps.train.learning_rate,
                                  runs=[weight_arena.param_order(MultiPeriodDiscriminator._arena_specs(self.net_d))], **kw)
         self._graph = None
+        # Sub-graphs run as side-stream branches (kernels.SideBranch).  "enc_p": the text encoder next to the posterior encoder +
+        # flow, forward and backward (-2.5 ms/step, replays bitwise reproducible).  Also available, OFF by default: "dp" (the
+        # stochastic duration predictor next to the decoder / discriminators: a further -2.6 ms, but in ~20 % of the replays the
+        # gradients of ONE of its ConvFlow layers come out ~1 % different — a race that was not found; ruled out: deferred slab
+        # reductions, shared scratch buffers, uninitialised global reads, the cross-stream gradient hand-off — DESIGN.md §6b) and
+        # "mel" (the mel of the generated waveform next to the discriminators: slower, 36.6 vs 34.5 ms).
+        self.side_branches = frozenset(("enc_p",))
         self.buckets_g = GradBuckets(self.net_g.parameters(), bucket_bytes)
         self.buckets_d = GradBuckets(self.net_d.parameters(), bucket_bytes)
         self.sched_g = torch.optim.lr_scheduler.ExponentialLR(self.optim_g, gamma=hps.train.lr_decay)
@@ -76,6 +84,10 @@ class FineTuner:
         hps = self.hps
         x, x_lengths, spec, spec_lengths, y, y_lengths, speakers = batch
         seg_frames = hps.train.segment_size // hps.data.hop_length
+        # side-stream branch of the duration predictor: not together with hook-mode bucket all-reduces (their packing copies
+        # would run on whichever stream a gradient arrives on)
+        branches = self.side_branches if (self.buckets_g.world == 1 or self.buckets_g._manual) else frozenset()
+        self.net_g.side_branches = branches
 
         with self._autocast():
             y_hat, l_length, attn, ids_slice, x_mask, z_mask, (z, z_p, m_p, logs_p, m_q, logs_q) = \
@@ -83,13 +95,23 @@ class FineTuner:
             mel = spec_to_mel_torch(spec.float(), hps.data.filter_length, hps.data.n_mel_channels, hps.data.sampling_rate,
                                     hps.data.mel_fmin, hps.data.mel_fmax)
             y_mel = commons.slice_segments(mel, ids_slice, seg_frames)
-            y_hat_mel = mel_spectrogram_torch(y_hat.squeeze(1), hps.data.filter_length, hps.data.n_mel_channels,
-                                              hps.data.sampling_rate, hps.data.hop_length, hps.data.win_length,
-                                              hps.data.mel_fmin, hps.data.mel_fmax)
+            # mel of the generated waveform as a side branch: its backward (generator step) then overlaps the discriminators'
+            mel_branch = K.SideBranch(y_hat.device, y_hat, lane=2) if ("mel" in branches and y_hat.is_cuda) else None
+            if mel_branch is not None:
+                mel_branch.__enter__()
+            try:
+                y_hat_mel = mel_spectrogram_torch(y_hat.squeeze(1), hps.data.filter_length, hps.data.n_mel_channels,
+                                                  hps.data.sampling_rate, hps.data.hop_length, hps.data.win_length,
+                                                  hps.data.mel_fmin, hps.data.mel_fmax)
+            finally:
+                if mel_branch is not None:
+                    mel_branch.__exit__(None, None, None)
             y = commons.slice_segments(y, ids_slice, hps.train.segment_size, ids_scale=hps.data.hop_length)
 
             # ---- discriminator step (finetune_speaker_v2.py:205-214)
             y_d_hat_r, y_d_hat_g, _, _ = self.net_d(y, y_hat.detach())
+            if mel_branch is not None:
+                y_hat_mel = mel_branch.join(y_hat_mel)
         loss_disc, losses_disc_r, losses_disc_g = discriminator_loss(y_d_hat_r, y_d_hat_g)
         self.buckets_d.zero_grad()
         loss_disc.backward()

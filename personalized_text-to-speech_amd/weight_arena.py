@@ -146,11 +146,34 @@ class WeightArena:
 
     @property
     def defer(self):
-        d = self.__dict__.get("_defer")
-        if d is None and self.w_fwd.is_cuda:
-            from . import kernels
-            d = self.__dict__["_defer"] = kernels.DeferredReductions(self.w_fwd.device)
-        return d
+        """The collector of deferred weight-gradient second stages for the CURRENT stream (a layer node resolves its weights —
+        and with them this collector — in its forward, and its backward runs on the same stream): a sub-graph that runs on a
+        side stream (kernels.SideBranch) gets its own collector, flushed on that stream by flush_deferred()."""
+        if not self.w_fwd.is_cuda:
+            return None
+        from . import kernels
+        cur = torch.cuda.current_stream(self.w_fwd.device)
+        defers = self.__dict__.setdefault("_defers", {})
+        hit = defers.get(cur.cuda_stream)
+        if hit is None:
+            hit = defers[cur.cuda_stream] = (kernels.DeferredReductions(self.w_fwd.device), cur)
+        return hit[0]
+
+    def flush_deferred(self):
+        """Run every collector's pending second stages, each on the stream its launches ran on; the current stream then waits
+        for the others (inside a capture: one join edge)."""
+        if not self.w_fwd.is_cuda:
+            return
+        cur = torch.cuda.current_stream(self.w_fwd.device)
+        for key, (d, stream) in list(self.__dict__.get("_defers", {}).items()):
+            if not d.pending:
+                continue
+            if key == cur.cuda_stream:
+                d.flush()
+            else:
+                with torch.cuda.stream(stream):
+                    d.flush()
+                cur.wait_stream(stream)
 
     def stale(self):
         """Parameters re-allocated (e.g. .to(device)) or replaced (remove_weight_norm folds weight_g / weight_v into `weight`)."""
@@ -167,8 +190,7 @@ class WeightArena:
 class PrepFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, arena, *params):
-        if arena.defer is not None:
-            arena.defer.flush()                      # leftovers of a backward that never reached this node
+        arena.flush_deferred()                       # leftovers of a backward that never reached this node
         arena.gen += 1
         arena.claimed.clear()
         ctx.gen = arena.gen
@@ -193,8 +215,7 @@ class PrepFn(torch.autograd.Function):
                 "weight_arena: this backward belongs to forward #%d, but forward #%d has since overwritten the arena's shared "
                 "operands and gradient buffers (two forwards of one network before a backward, e.g. loss(net(a)) + loss(net(b))): "
                 "run each forward's backward before the next forward, or batch the inputs" % (ctx.gen, arena.gen))
-        if arena.defer is not None:
-            arena.defer.flush()                      # the deferred second stages of this network's weight-gradient launches
+        arena.flush_deferred()                       # the deferred second stages of this network's weight-gradient launches
         arena.claimed.clear()
         # gradient accumulation (no zero_grad between two backwards): a param.grad that still aliases `dparam` would be
         # overwritten below and then added to itself by autograd — detach it into its own storage first

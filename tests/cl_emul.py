@@ -146,9 +146,19 @@ def convt_unfold(dy, t_in, k, u, pad):
     return torch.stack(cols, 2).reshape(b, t_in, k * c_out).to(dy.dtype).contiguous()
 
 
+def neg_cent(z_p, m_p, logs_p):
+    """vits_neg_cent: reference models.py:470-477 in fp32."""
+    import math
+    z_p, m_p, logs_p = z_p.detach().float(), m_p.detach().float(), logs_p.detach().float()
+    s = torch.exp(-2 * logs_p)
+    return (torch.sum(-0.5 * math.log(2 * math.pi) - logs_p, [1], keepdim=True) + torch.matmul(-0.5 * (z_p ** 2).transpose(1, 2), s)
+            + torch.matmul(z_p.transpose(1, 2), m_p * s) + torch.sum(-0.5 * (m_p ** 2) * s, [1], keepdim=True))
+
+
 def install(pkg):
     from importlib import import_module
     dcl = import_module("personalized_text-to-speech_amd.decoder_cl")
+    pkg.kernels.neg_cent = neg_cent
     pkg.kernels.conv1d_cl_raw = conv1d_cl_raw
     pkg.kernels.lrelu_mask_bwd = lrelu_mask_bwd
     pkg.kernels.colsum = colsum

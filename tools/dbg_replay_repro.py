@@ -7,7 +7,20 @@ from importlib import import_module
 P = import_module("personalized_text-to-speech_amd"); cfgs = import_module("personalized_text-to-speech_amd.configs"); tr = import_module("personalized_text-to-speech_amd.train")
 cfg_name, batch_size, t_y_range = cfgs.WORKLOADS[os.environ.get("WL", "C2")]
 hps = cfgs.get(cfg_name)
+X = os.environ.get("EXPERIMENT", "")
+if "nodefer" in X:                      # side-lane convolutions reduce their slabs immediately
+    WA = import_module("personalized_text-to-speech_amd.weight_arena")
+    main_defer = WA.WeightArena.defer
+    WA.WeightArena.defer = property(lambda self: None)
+if "freshws" in X:                      # no persistent scratch: a fresh buffer per call
+    K = P.kernels
+    K.workspace = lambda nbytes, device: torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+    import_module("personalized_text-to-speech_amd.rowops").K = K
+if "sync" in X:                         # every launch of the C library followed by a device-wide barrier on the host side
+    pass
 ft = tr.FineTuner(hps, "cuda:0", amp=os.environ.get("FP32") != "1")
+if os.environ.get("BRANCHES") is not None:
+    ft.side_branches = frozenset(b for b in os.environ["BRANCHES"].split(",") if b)
 batch = tr.synthetic_batch(hps, batch_size, t_y_range, "cuda:0")
 ft.capture(batch, warmup=3)
 ts = ft._state_tensors()
@@ -29,8 +42,9 @@ def run(fn):
             res["grad." + k] = p.grad.detach().clone()
     return res
 
-runs = [run(ft.replay) for _ in range(3)] + [run(lambda: ft.step(batch))]
-for i, name in ((1, "replay2"), (2, "replay3"), (3, "eager")):
+NR = int(os.environ.get("NREP", "3"))
+runs = [run(ft.replay) for _ in range(NR)] + [run(lambda: ft.step(batch))]
+for i, name in [(j, f"replay{j+1}") for j in range(1, NR)] + [(NR, "eager")]:
     diff = []
     for k in runs[0]:
         if k in runs[i] and not torch.equal(runs[0][k], runs[i][k]):

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Repeats FineTuner.verify_replay (two replays + one eager step from identical state, bitwise/1e-6 comparison) N times on the
+bench workload: a race between side-stream branches would show up as run-to-run differences."""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+from importlib import import_module
+P = import_module("personalized_text-to-speech_amd"); cfgs = import_module("personalized_text-to-speech_amd.configs"); tr = import_module("personalized_text-to-speech_amd.train")
+cfg_name, batch_size, t_y_range = cfgs.WORKLOADS["C2"]
+hps = cfgs.get(cfg_name)
+ft = tr.FineTuner(hps, "cuda:0", amp=True)
+if len(sys.argv) > 2:
+    ft.side_branches = frozenset(b for b in sys.argv[2].split(",") if b)
+batch = tr.synthetic_batch(hps, batch_size, t_y_range, "cuda:0")
+ft.capture(batch)
+bad = 0
+for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):
+    try:
+        ft.verify_replay()
+        print(i, "ok", {k: f"{v:.2e}" for k, v in ft.replay_vs_eager.items() if v > 0}, flush=True)
+    except RuntimeError as e:
+        bad += 1
+        print(i, "FAIL", str(e)[:300], flush=True)
+    ft.replay(); ft.replay()
+print("failures", bad)

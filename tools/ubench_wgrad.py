@@ -11,7 +11,10 @@ shapes = [  # b, t, ci, co, k, stride, dil, pad, in_slope
     (16, 256, 256, 256, 11, 1, 1, 5, 0.1), (16, 256, 256, 256, 3, 1, 1, 1, 0.1), (16, 4096, 64, 64, 11, 1, 1, 5, 0.1), (16, 4096, 64, 64, 3, 1, 1, 1, 0.1),
     (16, 201, 768, 192, 3, 1, 1, 1, 1.0), (16, 201, 192, 768, 3, 1, 1, 1, 1.0), (16, 500, 192, 384, 5, 1, 1, 2, 1.0), (16, 8192, 32, 32, 11, 1, 1, 5, 0.1),
 ]
-for (b, t, ci, co, kk, st, dl, pd, sl) in shapes:
+only = os.environ.get('UBW_ONLY')
+for idx, (b, t, ci, co, kk, st, dl, pd, sl) in enumerate(shapes):
+    if only and str(idx) not in only.split(','):
+        continue
     x = torch.randn(b, t, ci, device="cuda").bfloat16()
     t_out = (t + 2 * pd - dl * (kk - 1) - 1) // st + 1
     dy = torch.randn(b, t_out, co, device="cuda").bfloat16()
