@@ -59,5 +59,14 @@ for i, name in [(j, f"replay{j+1}") for j in range(1, NR)] + [(NR, "eager")]:
     print("   by kind:", kinds)
     for d, k in diff[:25]:
         print(f"   {d:.3e}  {k}")
+    if diff and os.environ.get("DETAIL"):
+        k = diff[0][1]
+        a, b = runs[0][k].double().flatten(), runs[i][k].double().flatten()
+        nz = (a != b).nonzero().flatten()
+        print(f"   detail {k}: shape {tuple(runs[0][k].shape)}, {nz.numel()} of {a.numel()} elements differ; first idx {nz[:12].tolist()}")
+        print("      a:", [f"{v:.4e}" for v in a[nz[:8]].tolist()]); print("      b:", [f"{v:.4e}" for v in b[nz[:8]].tolist()])
+        for kk in [d[1] for d in diff if "convs_sep.2.bias" in d[1] or "pre.weight" in d[1] or "pre.bias" in d[1]][:3]:
+            a2, b2 = runs[0][kk].double().flatten(), runs[i][kk].double().flatten()
+            print(f"   detail {kk}: {(a2 != b2).sum().item()} of {a2.numel()} differ, max rel {float(((a2-b2).abs()/(b2.abs()+1e-30)).max()):.2e}")
     outs = {k: (float(runs[0][k]), float(runs[i][k])) for k in runs[0] if k.startswith("out.")}
     print("   out:", {k: v for k, v in outs.items() if v[0] != v[1]})
