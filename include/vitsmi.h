@@ -398,6 +398,28 @@ int vits_adamw(float* p, float* m, float* v, const vits_adamw_entry* host_entrie
 int vits_gradnorm_final(const float* partials, size_t n, float* norm_out, float* state, int bump_step, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Feature-matching loss over all feature maps of all discriminators in one pass (csrc/reduce.hip).
+ *
+ * Replaces: losses.feature_loss (losses.py:7-15): for every feature map `torch.mean(torch.abs(rl.detach() - gl))`, summed,
+ *           times 2 — 37 maps per step, each a subtraction, abs, mean and add, plus their autograd.
+ *   item e : h = one feature map, contiguous, 2 n elements: first half the real items, second half the generated ones;
+ *            scale = 2 / (elements of one half, not counting zero padding channels);  dh (backward only): same shape,
+ *            every element written (the real half gets zeros: the reference detaches it);
+ *   out[0] = sum_e scale_e * sum |real - generated|   (fixed summation order);   g: device float, gradient of out[0];
+ *   host_items is a HOST array (passed on by value), n_items <= 48.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const void* h;
+  void* dh;
+  size_t n;
+  float scale;
+} vits_feat_item;
+size_t vits_feature_l1_workspace(int n_items);
+int vits_feature_l1(int dtype, const vits_feat_item* host_items, int n_items, float* out, void* workspace, size_t workspace_bytes,
+                    void* stream);
+int vits_feature_l1_bwd(int dtype, const vits_feat_item* host_items, int n_items, const float* g, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Least-squares GAN losses over the logits of all discriminators in one pass (csrc/reduce.hip).
  *
  * Replaces: losses.discriminator_loss (losses.py:18-32) and losses.generator_loss (losses.py:35-43): per discriminator

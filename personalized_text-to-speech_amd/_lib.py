@@ -61,6 +61,9 @@ SIGNATURES = {
     "vits_adamw_blocks": (c_size_t, [c_void_p, c_int]),
     "vits_adamw": (c_int, [c_void_p] * 4 + [c_int, c_void_p] + [ctypes.c_double] * 4 + [c_void_p, c_size_t, c_void_p]),
     "vits_gradnorm_final": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_int, c_void_p]),
+    "vits_feature_l1_workspace": (c_size_t, [c_int]),
+    "vits_feature_l1": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "vits_feature_l1_bwd": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "vits_lsgan_workspace": (c_size_t, [c_int]),
     "vits_lsgan_loss": (c_int, [c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "vits_lsgan_loss_bwd": (c_int, [c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
@@ -82,6 +85,11 @@ class PrepEntry(ctypes.Structure):
     """vits_prep_entry of include/vitsmi.h"""
     _fields_ = [("v", c_void_p), ("g", c_void_p), ("off", ctypes.c_int64), ("off_dv", ctypes.c_int64), ("off_dg", ctypes.c_int64)] + \
                [(n, ctypes.c_int32) for n in ("layout", "c_out", "c_in", "k", "c_out_p", "c_in_p", "row_lo", "n_rows", "row0", "groups")]
+
+
+class FeatItem(ctypes.Structure):
+    """vits_feat_item of include/vitsmi.h"""
+    _fields_ = [("h", c_void_p), ("dh", c_void_p), ("n", c_size_t), ("scale", c_float)]
 
 
 class LsganItem(ctypes.Structure):

@@ -203,6 +203,128 @@ int pick_splits(size_t seg_len, int n_seg) {
 
 namespace {
 
+// ---- feature-matching loss over ALL feature maps of all discriminators in one pass (losses.py:7-15) ----------------------------
+// entry e: h [2 n_e] (first half real, second half generated), scale_e = 2 / (elements of one half without padding channels).
+constexpr int kFeatMax = 48, kFeatSplits = 64;
+struct FeatTable { const void* h[kFeatMax]; void* dh[kFeatMax]; unsigned long long n[kFeatMax]; float scale[kFeatMax]; int count; };
+
+// grid (kFeatSplits, entries): partial[e * kFeatSplits + split] = scale_e * sum over the split's slice of |a - b|
+template <typename T>
+__global__ __launch_bounds__(kThreads) void feat_partial_kernel(FeatTable tab, float* __restrict__ partial) {
+  __shared__ float red[4];
+  const int e = blockIdx.y;
+  const size_t n = tab.n[e];
+  const T* a = static_cast<const T*>(tab.h[e]);
+  const T* b = a + n;
+  float acc = 0.f;
+  if (sizeof(T) == 2 && n % 8 == 0 && (reinterpret_cast<uintptr_t>(a) & 15) == 0) {
+    const u32x4* av = reinterpret_cast<const u32x4*>(a);
+    const u32x4* bv = reinterpret_cast<const u32x4*>(b);
+    const size_t nvec = n / 8;
+#pragma unroll 2
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += (size_t)kFeatSplits * kThreads) {
+      Bf8 x, y;
+      x.u = av[i]; y.u = bv[i];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc += fabsf((float)x.e[j] - (float)y.e[j]);
+    }
+  } else {
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (size_t)kFeatSplits * kThreads) acc += fabsf(ld<T>(a, i) - ld<T>(b, i));
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) partial[(size_t)e * kFeatSplits + blockIdx.x] = acc * tab.scale[e];
+}
+
+// out = sum of all partials, entry by entry, split by split (fixed order)
+__global__ __launch_bounds__(64) void feat_final_kernel(const float* __restrict__ partial, int count, float* __restrict__ out) {
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < count * kFeatSplits; i += 64) acc += partial[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (threadIdx.x == 0) out[0] = acc;
+}
+
+// d(generated half) = -sign(a - b) * scale_e * g, d(real half) = 0 (the reference detaches it, losses.py:11); every element written
+template <typename T>
+__global__ __launch_bounds__(kThreads) void feat_bwd_kernel(FeatTable tab, const float* __restrict__ g) {
+  const int e = blockIdx.y;
+  const size_t n = tab.n[e];
+  const T* a = static_cast<const T*>(tab.h[e]);
+  const T* b = a + n;
+  T* da = static_cast<T*>(tab.dh[e]);
+  T* db = da + n;
+  const float gs = g[0] * tab.scale[e];
+  if (sizeof(T) == 2 && n % 8 == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(da)) & 15) == 0) {
+    const u32x4* av = reinterpret_cast<const u32x4*>(a);
+    const u32x4* bv = reinterpret_cast<const u32x4*>(b);
+    u32x4* dav = reinterpret_cast<u32x4*>(da);
+    u32x4* dbv = reinterpret_cast<u32x4*>(db);
+    const size_t nvec = n / 8;
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += (size_t)gridDim.x * kThreads) {
+      Bf8 x, y, o;
+      x.u = av[i]; y.u = bv[i];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float d = (float)x.e[j] - (float)y.e[j];
+        o.e[j] = (__bf16)(d > 0.f ? -gs : (d < 0.f ? gs : 0.f));
+      }
+      dbv[i] = o.u;
+      dav[i] = u32x4{0u, 0u, 0u, 0u};
+    }
+  } else {
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (size_t)gridDim.x * kThreads) {
+      const float d = ld<T>(a, i) - ld<T>(b, i);
+      db[i] = (T)(d > 0.f ? -gs : (d < 0.f ? gs : 0.f));
+      da[i] = (T)0.f;
+    }
+  }
+}
+
+int feat_table(const vits_feat_item* items, int n_items, FeatTable& tab, bool need_dh) {
+  if (!items || n_items <= 0 || n_items > kFeatMax) return VITS_E_BADARG;
+  tab.count = n_items;
+  for (int i = 0; i < n_items; ++i) {
+    if (!items[i].h || items[i].n == 0 || (need_dh && !items[i].dh)) return VITS_E_BADARG;
+    tab.h[i] = items[i].h; tab.dh[i] = items[i].dh; tab.n[i] = items[i].n; tab.scale[i] = items[i].scale;
+  }
+  return VITS_OK;
+}
+
+}  // namespace
+
+extern "C" size_t vits_feature_l1_workspace(int n_items) { return (size_t)n_items * kFeatSplits * sizeof(float); }
+
+extern "C" int vits_feature_l1(int dtype, const vits_feat_item* host_items, int n_items, float* out, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+  FeatTable tab;
+  const int rc = feat_table(host_items, n_items, tab, false);
+  if (rc != VITS_OK) return rc;
+  if (!out || !workspace || workspace_bytes < vits_feature_l1_workspace(n_items)) return VITS_E_BADARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float* partial = static_cast<float*>(workspace);
+  const dim3 grid(kFeatSplits, n_items);
+  if (dtype == VITS_DT_BF16) hipLaunchKernelGGL(feat_partial_kernel<__bf16>, grid, dim3(kThreads), 0, s, tab, partial);
+  else if (dtype == VITS_DT_F32) hipLaunchKernelGGL(feat_partial_kernel<float>, grid, dim3(kThreads), 0, s, tab, partial);
+  else return VITS_E_UNSUPPORTED;
+  hipLaunchKernelGGL(feat_final_kernel, dim3(1), dim3(64), 0, s, partial, n_items, out);
+  return vits::check_launch("vits_feature_l1");
+}
+
+extern "C" int vits_feature_l1_bwd(int dtype, const vits_feat_item* host_items, int n_items, const float* g, void* stream) {
+  FeatTable tab;
+  const int rc = feat_table(host_items, n_items, tab, true);
+  if (rc != VITS_OK) return rc;
+  if (!g) return VITS_E_BADARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid(96, n_items);
+  if (dtype == VITS_DT_BF16) hipLaunchKernelGGL(feat_bwd_kernel<__bf16>, grid, dim3(kThreads), 0, s, tab, g);
+  else if (dtype == VITS_DT_F32) hipLaunchKernelGGL(feat_bwd_kernel<float>, grid, dim3(kThreads), 0, s, tab, g);
+  else return VITS_E_UNSUPPORTED;
+  return vits::check_launch("vits_feature_l1_bwd");
+}
+
+namespace {
+
 // ---- least-squares GAN losses over the logits of all discriminators (losses.py:18-43) -----------------------------------
 // item d: y8 [J][R][8], channel 0 live, items j < J/2 real, the rest generated.
 //   mode 0 (discriminator_loss): sum_d mean_real (1 - y)^2 + mean_gen y^2       mode 1 (generator_loss): sum_d mean_gen (1 - y)^2

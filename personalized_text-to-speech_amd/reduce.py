@@ -54,44 +54,44 @@ def sum_all(x):
 
 
 class _FeatureL1(torch.autograd.Function):
+    """All feature maps in one pass (vits_feature_l1[_bwd]): two launches forward, one backward."""
+
+    @staticmethod
+    def _items(hs, dens, dhs=None):
+        items = (_lib.FeatItem * len(hs))()
+        for i, h in enumerate(hs):
+            items[i].h, items[i].dh = h.data_ptr(), (None if dhs is None else dhs[i].data_ptr())
+            items[i].n, items[i].scale = h.numel() // 2, 2.0 / dens[i]
+        return items
+
     @staticmethod
     def forward(ctx, dens, *hs):
+        import ctypes
         L = _lib.lib()
-        dev = hs[0].device
+        hd = [h.detach() for h in hs]
+        assert 0 < len(hd) <= 48 and all(h.is_contiguous() and h.size(0) % 2 == 0 and h.dtype == hd[0].dtype and h.dtype in _DT for h in hd)
+        _lib.require_cuda(*hd)
+        dev = hd[0].device
         out = torch.empty(1, device=dev, dtype=torch.float32)
-        ws, nbytes = _ws(1, dev)
-        saved = []
-        for i, h in enumerate(hs):
-            hd = h.detach()
-            assert hd.is_contiguous() and hd.size(0) % 2 == 0 and hd.dtype in _DT
-            _lib.require_cuda(hd)
-            n = hd.numel() // 2
-            es = hd.element_size()
-            rc = L.vits_absdiff_sum(_DT[hd.dtype], hd.data_ptr(), hd.data_ptr() + n * es, n, 2.0 / dens[i], out.data_ptr(), 1 if i else 0,
-                                    ws.data_ptr(), nbytes, _lib.stream_ptr())
-            _lib.check(rc, "vits_absdiff_sum")
-            saved.append(hd)
-        ctx.save_for_backward(*saved)
+        nbytes = L.vits_feature_l1_workspace(len(hd))
+        ws = K.workspace(nbytes, dev)
+        items = _FeatureL1._items(hd, dens)
+        _lib.check(L.vits_feature_l1(_DT[hd[0].dtype], ctypes.addressof(items), len(hd), out.data_ptr(), ws.data_ptr(), nbytes, _lib.stream_ptr()),
+                   "vits_feature_l1")
+        ctx.save_for_backward(*hd)
         ctx.dens = dens
         return out.view(())
 
     @staticmethod
     def backward(ctx, g):
-        L = _lib.lib()
+        import ctypes
+        hd = ctx.saved_tensors
         gf = g.detach().float().contiguous().view(1)
-        grads = []
-        for i, hd in enumerate(ctx.saved_tensors):
-            if not ctx.needs_input_grad[i + 1]:
-                grads.append(None)
-                continue
-            n = hd.numel() // 2
-            es = hd.element_size()
-            dh = torch.empty_like(hd)
-            rc = L.vits_absdiff_bwd(_DT[hd.dtype], hd.data_ptr(), hd.data_ptr() + n * es, n, gf.data_ptr(), 2.0 / ctx.dens[i],
-                                    dh.data_ptr(), dh.data_ptr() + n * es, _lib.stream_ptr())
-            _lib.check(rc, "vits_absdiff_bwd")
-            grads.append(dh)
-        return (None, *grads)
+        dhs = [torch.empty_like(h) for h in hd]
+        items = _FeatureL1._items(hd, ctx.dens, dhs)
+        _lib.check(_lib.lib().vits_feature_l1_bwd(_DT[hd[0].dtype], ctypes.addressof(items), len(hd), gf.data_ptr(), _lib.stream_ptr()),
+                   "vits_feature_l1_bwd")
+        return (None, *[d if ctx.needs_input_grad[i + 1] else None for i, d in enumerate(dhs)])
 
 
 def feature_l1(hs, dens=None):
