@@ -487,6 +487,8 @@ class SynthesizerTrn(nn.Module):
 
         def wn_specs(wn):
             H, out = wn.hidden_channels, []
+            if wn.gin_channels != 0 and wn.gin_channels % 8 == 0:
+                out.append(Spec(wn.cond_layer, bias=True))     # speaker conditioning of all layers: one [b,1,gin] x [gin, 2HL] product
             for i in range(wn.n_layers):
                 out.append(Spec(wn.in_layers[i]))
                 out.append(Spec(wn.res_skip_layers[i]))        # rows [0, H) residual, [H, 2H) skip: one operand, one gradient launch

@@ -157,7 +157,12 @@ def wn_cond(wn, g, n_items):
     """cond_layer(g) (modules.py:152-153) as [L][b][2H] float32, or None."""
     if g is None:
         return None
-    c = torch.nn.functional.linear(g[:, :, 0].float(), wn.cond_layer.weight[:, :, 0].float(), wn.cond_layer.bias.float())
+    if g.is_cuda and WA.handle_for(wn.cond_layer) is not None:
+        # arena-managed: weight-norm by the arena's preparation launch, the product and both gradients on the convolution kernels
+        dt = compute_dtype()
+        c = conv_cl(g[:, :, 0].unsqueeze(1).to(dt), weight_of(wn.cond_layer), bias_of(wn.cond_layer), dtype=dt).float()      # [b, 1, 2HL]
+    else:
+        c = torch.nn.functional.linear(g[:, :, 0].float(), wn.cond_layer.weight[:, :, 0].float(), wn.cond_layer.bias.float())
     return c.view(n_items, wn.n_layers, 2 * wn.hidden_channels).transpose(0, 1).contiguous()
 
 
