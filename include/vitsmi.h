@@ -398,6 +398,37 @@ int vits_adamw(float* p, float* m, float* v, const vits_adamw_entry* host_entrie
 int vits_gradnorm_final(const float* partials, size_t n, float* norm_out, float* state, int bump_step, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The two-channel flows of the stochastic duration predictor without their glue (csrc/rq_spline.hip, csrc/flow_edge.hip).
+ *
+ * Replaces, per modules.ConvFlow layer (modules.py:346-390) and the modules.Flip after it (modules.py:273-279):
+ *   - `x0, x1 = torch.split(x, ...)`, `self.pre(x0)` (Conv1d(1, C, 1)) and the `x + g` of DDSConv.forward (modules.py:96):
+ *       vits_flow_front:      h[r][c] = x[r][c0] * w[c] + bias[c] (+ g[r][c])       x fp32 [rows][xs], xs = 1 | 2; h, g `dtype`
+ *       vits_flow_front_bwd:  dx [rows][xs] (channel c0 = sum_c dh w, the other 0), dw[c] = sum_r dh x, db[c] = sum_r dh
+ *   - the spline call with `x = torch.cat([x0, x1], 1) * x_mask` and `logdet = torch.sum(logabsdet * x_mask, [1, 2])` around it:
+ *       vits_flow_spline:     y2[r][c1] = spline(x2[r][c1]; h[r]) * mask[r],  y2[r][1-c1] = x2[r][1-c1] * mask[r],
+ *                             lad_masked[r] = logabsdet[r] * mask[r]          (sum it per item with vits_segsum_f32)
+ *       vits_flow_spline_bwd: dx2, gh from dy2 [rows][2] and dlogdet [rows / t] (per item)
+ *   - Flip: alternate c1 between consecutive layers instead of reversing the two channels in memory.
+ * ------------------------------------------------------------------------------------------ */
+/* Mean-only residual coupling layer (modules.py:330-343) + the Flip after it (modules.py:273-279), element-wise part:
+ *   y = flip_channels([x0, stats + x1 * mask])  (flip = 0: no flip);  x, y [b][t][c], stats [b][t][c - half], mask = t < lengths[b];
+ *   backward: dx and dstats from dy. */
+int vits_coupling_tail(int dtype, const void* x, const void* stats, const int32_t* lengths, void* y, int b, int t, int c, int half, int flip,
+                       void* stream);
+int vits_coupling_tail_bwd(int dtype, const void* dy, const int32_t* lengths, void* dx, void* dstats, int b, int t, int c, int half, int flip,
+                           void* stream);
+int vits_flow_front(int dtype, const float* x, int xs, int c0, const float* w, const float* bias, const void* g, void* h, int rows,
+                    int c, void* stream);
+size_t vits_flow_front_workspace(int rows, int c);
+int vits_flow_front_bwd(int dtype, const float* x, int xs, int c0, const float* w, const void* dh, float* dx, float* dw, float* db,
+                        void* workspace, size_t workspace_bytes, int rows, int c, void* stream);
+int vits_flow_spline(int h_dtype, const float* x2, const void* h, int ldh, float hscale, int inverse, float tail_bound,
+                     const float* mask, int c1, float* y2, float* lad_masked, int n, void* stream);
+int vits_flow_spline_bwd(int h_dtype, const float* x2, const void* h, int ldh, float hscale, int inverse, float tail_bound,
+                         const float* mask, int c1, const float* dy2, const float* dlogdet, int t, float* dx2, void* gh, int n,
+                         void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Feature-matching loss over all feature maps of all discriminators in one pass (csrc/reduce.hip).
  *
  * Replaces: losses.feature_loss (losses.py:7-15): for every feature map `torch.mean(torch.abs(rl.detach() - gl))`, summed,

@@ -61,6 +61,14 @@ SIGNATURES = {
     "vits_adamw_blocks": (c_size_t, [c_void_p, c_int]),
     "vits_adamw": (c_int, [c_void_p] * 4 + [c_int, c_void_p] + [ctypes.c_double] * 4 + [c_void_p, c_size_t, c_void_p]),
     "vits_gradnorm_final": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_int, c_void_p]),
+    "vits_coupling_tail": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
+    "vits_coupling_tail_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
+    "vits_flow_front": (c_int, [c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "vits_flow_front_workspace": (c_size_t, [c_int, c_int]),
+    "vits_flow_front_bwd": (c_int, [c_int, c_void_p, c_int, c_int] + [c_void_p] * 6 + [c_size_t, c_int, c_int, c_void_p]),
+    "vits_flow_spline": (c_int, [c_int, c_void_p, c_void_p, c_int, c_float, c_int, c_float, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "vits_flow_spline_bwd": (c_int, [c_int, c_void_p, c_void_p, c_int, c_float, c_int, c_float, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                     c_void_p, c_void_p, c_int, c_void_p]),
     "vits_feature_l1_workspace": (c_size_t, [c_int]),
     "vits_feature_l1": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "vits_feature_l1_bwd": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p]),

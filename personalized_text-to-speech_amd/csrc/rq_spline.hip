@@ -73,19 +73,31 @@ __device__ __forceinline__ void knots_bwd(const Knots& k, int i, float g_lo, flo
   for (int m = 0; m < NB; ++m) g_u[m] = k.p[m] * (gp[m] - dot);
 }
 
-template <typename TH, bool BWD>
+// FLOW = the element lives in a two-channel flow state (modules.ConvFlow, modules.py:346-390): x / y / gy / gx are [n][2] tensors,
+// channel c1 is transformed, channel 1 - c1 passes through, everything is multiplied by the row mask m[n], and the
+// log-determinant leaves as lad[n] * m[n] (its per-item sum is a separate launch).  The gradient of that sum arrives per ITEM
+// (dlogdet[e / t]).  This replaces the slice / cat / mask / cast glue around the spline (and, with c1 alternating from layer to
+// layer, the physical channel flips between the layers).
+struct FlowIO { const float* m; const float* dlogdet; int t; int c1; };
+
+template <typename TH, bool BWD, bool FLOW>
 __global__ void spline_kernel(const float* __restrict__ x, const TH* __restrict__ h, int ldh, float hscale, int inverse, float B,
                               float* __restrict__ y, float* __restrict__ lad, const float* __restrict__ gy,
-                              const float* __restrict__ gl, float* __restrict__ gx, TH* __restrict__ gh, int n) {
+                              const float* __restrict__ gl, float* __restrict__ gx, TH* __restrict__ gh, int n, FlowIO io) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
-  const float xv = x[e];
+  const int ix = FLOW ? 2 * e + io.c1 : e, ip = FLOW ? 2 * e + 1 - io.c1 : e;      // transformed / pass-through element
+  const float mv = FLOW ? io.m[e] : 1.f;
+  const float xv = x[ix];
   const TH* hr = h + (size_t)e * ldh;
   const bool inside = (xv >= -B) && (xv <= B);
   if (!inside) {
-    if (!BWD) { y[e] = xv; lad[e] = 0.f; }
-    else {
-      gx[e] = gy[e];
+    if (!BWD) {
+      y[ix] = xv * mv; lad[e] = 0.f;
+      if (FLOW) y[ip] = x[ip] * mv;
+    } else {
+      gx[ix] = gy[ix] * mv;
+      if (FLOW) gx[ip] = gy[ip] * mv;
       for (int j = 0; j < ldh; ++j) gh[(size_t)e * ldh + j] = from_f<TH>(0.f);
     }
     return;
@@ -138,12 +150,13 @@ __global__ void spline_kernel(const float* __restrict__ x, const TH* __restrict_
   const float l = logf(dnum) - 2.f * logf(den);
   if (!inverse) out = CH + num / den; else out = theta * W + CW;
   if (!BWD) {
-    y[e] = out;
-    lad[e] = inverse ? -l : l;
+    y[ix] = out * mv;
+    lad[e] = (inverse ? -l : l) * mv;
+    if (FLOW) y[ip] = x[ip] * mv;
     return;
   }
   // ------------------------------------------------------------------ reverse mode
-  const float gyv = gy[e], glv = gl[e];
+  const float gyv = gy[ix] * mv, glv = FLOW ? io.dlogdet[e / io.t] * mv : gl[e];
   float g_theta = 0.f, g_q = 0.f, g_delta = 0.f, g_s = 0.f, g_d0 = 0.f, g_d1 = 0.f, g_H = 0.f, g_W = 0.f, g_CW = 0.f, g_CH = 0.f;
   float g_x = 0.f;
   float g_dnum, g_den;
@@ -204,7 +217,8 @@ __global__ void spline_kernel(const float* __restrict__ x, const TH* __restrict_
   float g_uw[NB], g_uh[NB];
   knots_bwd(kw, i, g_CW - g_W, g_W, B, g_uw);
   knots_bwd(kh, i, g_CH - g_H, g_H, B, g_uh);
-  gx[e] = g_x;
+  gx[ix] = g_x;
+  if (FLOW) gx[ip] = gy[ip] * mv;
   TH* gr = gh + (size_t)e * ldh;
 #pragma unroll
   for (int j = 0; j < NB; ++j) { gr[j] = from_f<TH>(g_uw[j] * hscale); gr[NB + j] = from_f<TH>(g_uh[j] * hscale); }
@@ -226,9 +240,9 @@ extern "C" int vits_rq_spline(int h_dtype, const float* x, const void* h, int ld
   hipStream_t s = static_cast<hipStream_t>(stream);
   dim3 grid((n + 127) / 128), block(128);
   if (h_dtype == VITS_DT_F32)
-    hipLaunchKernelGGL((spline_kernel<float, false>), grid, block, 0, s, x, (const float*)h, ldh, hscale, inverse, tail_bound, y, logabsdet, nullptr, nullptr, nullptr, (float*)nullptr, n);
+    hipLaunchKernelGGL((spline_kernel<float, false, false>), grid, block, 0, s, x, (const float*)h, ldh, hscale, inverse, tail_bound, y, logabsdet, nullptr, nullptr, nullptr, (float*)nullptr, n, FlowIO{});
   else if (h_dtype == VITS_DT_BF16)
-    hipLaunchKernelGGL((spline_kernel<__bf16, false>), grid, block, 0, s, x, (const __bf16*)h, ldh, hscale, inverse, tail_bound, y, logabsdet, nullptr, nullptr, nullptr, (__bf16*)nullptr, n);
+    hipLaunchKernelGGL((spline_kernel<__bf16, false, false>), grid, block, 0, s, x, (const __bf16*)h, ldh, hscale, inverse, tail_bound, y, logabsdet, nullptr, nullptr, nullptr, (__bf16*)nullptr, n, FlowIO{});
   else return VITS_E_UNSUPPORTED;
   return vits::check_launch("vits_rq_spline");
 }
@@ -239,9 +253,41 @@ extern "C" int vits_rq_spline_bwd(int h_dtype, const float* x, const void* h, in
   hipStream_t s = static_cast<hipStream_t>(stream);
   dim3 grid((n + 127) / 128), block(128);
   if (h_dtype == VITS_DT_F32)
-    hipLaunchKernelGGL((spline_kernel<float, true>), grid, block, 0, s, x, (const float*)h, ldh, hscale, inverse, tail_bound, nullptr, nullptr, gy, glogabsdet, gx, (float*)gh, n);
+    hipLaunchKernelGGL((spline_kernel<float, true, false>), grid, block, 0, s, x, (const float*)h, ldh, hscale, inverse, tail_bound, nullptr, nullptr, gy, glogabsdet, gx, (float*)gh, n, FlowIO{});
   else if (h_dtype == VITS_DT_BF16)
-    hipLaunchKernelGGL((spline_kernel<__bf16, true>), grid, block, 0, s, x, (const __bf16*)h, ldh, hscale, inverse, tail_bound, nullptr, nullptr, gy, glogabsdet, gx, (__bf16*)gh, n);
+    hipLaunchKernelGGL((spline_kernel<__bf16, true, false>), grid, block, 0, s, x, (const __bf16*)h, ldh, hscale, inverse, tail_bound, nullptr, nullptr, gy, glogabsdet, gx, (__bf16*)gh, n, FlowIO{});
   else return VITS_E_UNSUPPORTED;
   return vits::check_launch("vits_rq_spline_bwd");
+}
+
+// ---- the spline inside a two-channel flow state (see FlowIO above) -------------------------------------------------------
+extern "C" int vits_flow_spline(int h_dtype, const float* x2, const void* h, int ldh, float hscale, int inverse, float tail_bound,
+                                const float* mask, int c1, float* y2, float* lad_masked, int n, void* stream) {
+  if (!x2 || !h || !mask || !y2 || !lad_masked || n <= 0 || ldh < 29 || !(tail_bound > 0.f) || (c1 != 0 && c1 != 1)) return VITS_E_BADARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  dim3 grid((n + 127) / 128), block(128);
+  const FlowIO io{mask, nullptr, 1, c1};
+  if (h_dtype == VITS_DT_F32)
+    hipLaunchKernelGGL((spline_kernel<float, false, true>), grid, block, 0, s, x2, (const float*)h, ldh, hscale, inverse, tail_bound, y2, lad_masked, nullptr, nullptr, nullptr, (float*)nullptr, n, io);
+  else if (h_dtype == VITS_DT_BF16)
+    hipLaunchKernelGGL((spline_kernel<__bf16, false, true>), grid, block, 0, s, x2, (const __bf16*)h, ldh, hscale, inverse, tail_bound, y2, lad_masked, nullptr, nullptr, nullptr, (__bf16*)nullptr, n, io);
+  else return VITS_E_UNSUPPORTED;
+  return vits::check_launch("vits_flow_spline");
+}
+
+extern "C" int vits_flow_spline_bwd(int h_dtype, const float* x2, const void* h, int ldh, float hscale, int inverse, float tail_bound,
+                                    const float* mask, int c1, const float* dy2, const float* dlogdet, int t, float* dx2, void* gh, int n,
+                                    void* stream) {
+  if (!x2 || !h || !mask || !dy2 || !dlogdet || !dx2 || !gh || n <= 0 || t <= 0 || n % t != 0 || ldh < 29 || !(tail_bound > 0.f) ||
+      (c1 != 0 && c1 != 1))
+    return VITS_E_BADARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  dim3 grid((n + 127) / 128), block(128);
+  const FlowIO io{mask, dlogdet, t, c1};
+  if (h_dtype == VITS_DT_F32)
+    hipLaunchKernelGGL((spline_kernel<float, true, true>), grid, block, 0, s, x2, (const float*)h, ldh, hscale, inverse, tail_bound, nullptr, nullptr, dy2, nullptr, dx2, (float*)gh, n, io);
+  else if (h_dtype == VITS_DT_BF16)
+    hipLaunchKernelGGL((spline_kernel<__bf16, true, true>), grid, block, 0, s, x2, (const __bf16*)h, ldh, hscale, inverse, tail_bound, nullptr, nullptr, dy2, nullptr, dx2, (__bf16*)gh, n, io);
+  else return VITS_E_UNSUPPORTED;
+  return vits::check_launch("vits_flow_spline_bwd");
 }

@@ -60,21 +60,29 @@ class StochasticDurationPredictor(nn.Module):
         xc = self.convs.forward_cl(xc, lengths, m)
         xc = wn_cl.conv_cl(xc, wn_cl.weight_of(self.proj), wn_cl.bias_of(self.proj), lengths, mask_out=True, dtype=dtype)
 
+        # modules.Flip (reverse the two channels) is not executed: `swap` records the parity of the flips so far, the ConvFlow
+        # layers exchange the roles of the two channels instead, and the element-wise layers index their parameters accordingly
+        state = {"swap": False}
+
         def run(flow, z, cond):
             if isinstance(flow, modules.Flip):
-                return torch.flip(z, [2]), None
+                state["swap"] = not state["swap"]
+                return z, None
             if isinstance(flow, modules.ElementwiseAffine):
                 mm, ls = flow.m.view(1, 1, -1), flow.logs.view(1, 1, -1)
+                if state["swap"]:
+                    mm, ls = mm.flip(-1), ls.flip(-1)
                 if not reverse:
                     return (mm + torch.exp(ls) * z) * m, commons.sum12(ls * m)
                 return (z - mm) * torch.exp(-ls) * m, None
-            out = flow.forward_cl(z, lengths, m, cond, reverse)
+            out = flow.forward_cl(z, lengths, m, cond, reverse, swap=state["swap"])
             return (out[0], out[1]) if not reverse else (out, None)
 
         if not reverse:
             assert w is not None
             w_cl = w.transpose(1, 2).float()                           # [b, t, 1]
-            h_w = wn_cl.conv_cl(F.pad(w_cl, (0, 7)).to(dtype), wn_cl.weight_of(self.post_pre, pad_in=7), wn_cl.bias_of(self.post_pre), dtype=dtype)
+            from . import rowops
+            h_w = rowops.flow_front(w_cl, 0, self.post_pre.weight, self.post_pre.bias, None, dtype)       # Conv1d(1, C, 1) on the durations
             h_w = self.post_convs.forward_cl(h_w, lengths, m)
             h_w = wn_cl.conv_cl(h_w, wn_cl.weight_of(self.post_proj), wn_cl.bias_of(self.post_proj), lengths, mask_out=True, dtype=dtype)
             e_q = noise.randn(w.size(0), 2, w.size(2), device=x.device, dtype=torch.float32).transpose(1, 2) * m
@@ -84,6 +92,7 @@ class StochasticDurationPredictor(nn.Module):
                 z_q, ld = run(flow, z_q, cond_q)
                 if ld is not None:
                     logdet_tot_q = logdet_tot_q + ld
+            assert not state["swap"]                                   # an even number of flips: natural channel order
             z_u, z1 = z_q[..., :1], z_q[..., 1:]
             u = torch.sigmoid(z_u) * m
             z0 = (w_cl - u) * m
@@ -104,7 +113,8 @@ class StochasticDurationPredictor(nn.Module):
         z = noise.randn(x.size(0), 2, x.size(2), device=x.device, dtype=torch.float32).transpose(1, 2) * noise_scale
         for flow in flows:
             z, _ = run(flow, z, xc)
-        return z[..., :1].transpose(1, 2).to(x.dtype)                  # logw [b, 1, t]
+        z0 = z[..., 1:] if state["swap"] else z[..., :1]               # channel 0 of the (virtually flipped) state
+        return z0.transpose(1, 2).to(x.dtype)                          # logw [b, 1, t]
 
 
 class DurationPredictor(nn.Module):
@@ -212,11 +222,17 @@ class ResidualCouplingBlock(nn.Module):
         lengths = x_mask[:, 0, :].sum(-1).to(torch.int32)
         h = x.transpose(1, 2).contiguous()
         if not reverse:
-            for flow in self.flows:
+            flows = list(self.flows)
+            i = 0
+            while i < len(flows):
+                flow = flows[i]
                 if isinstance(flow, modules.Flip):
                     h = torch.flip(h, [2])
-                else:
-                    h, _ = flow.forward_cl(h, lengths, mask_cl, g=g, reverse=False)
+                    i += 1
+                    continue
+                fold = i + 1 < len(flows) and isinstance(flows[i + 1], modules.Flip)       # the Flip after a coupling layer rides in its tail kernel
+                h, _ = flow.forward_cl(h, lengths, mask_cl, g=g, reverse=False, flip_after=fold)
+                i += 2 if fold else 1
         else:
             for flow in reversed(self.flows):
                 if isinstance(flow, modules.Flip):
@@ -507,12 +523,11 @@ class SynthesizerTrn(nn.Module):
         # stochastic duration predictor: every 192-channel 1x1 convolution; the 29-column spline projections padded to 32
         if isinstance(net.dp, StochasticDurationPredictor):
             dp = net.dp
-            specs += [Spec(dp.pre, bias=True), Spec(dp.proj, bias=True), Spec(dp.post_proj, bias=True), Spec(dp.post_pre, c_in_p=8, bias=True)]
+            specs += [Spec(dp.pre, bias=True), Spec(dp.proj, bias=True), Spec(dp.post_proj, bias=True)]
             specs += dds_specs(dp.convs) + dds_specs(dp.post_convs)
             for fl in list(dp.flows) + list(dp.post_flows):
                 if isinstance(fl, modules.ConvFlow):
-                    specs += dds_specs(fl.convs) + [Spec(fl.pre, c_in_p=8, bias=True),
-                                                    Spec(fl.proj, c_out_p=(fl.proj.out_channels + 7) // 8 * 8, bias=True)]
+                    specs += dds_specs(fl.convs) + [Spec(fl.proj, c_out_p=(fl.proj.out_channels + 7) // 8 * 8, bias=True)]
         for fl in net.flow.flows:
             if isinstance(fl, modules.ResidualCouplingLayer):
                 specs += [Spec(fl.pre, bias=True)] + wn_specs(fl.enc) + [Spec(fl.post, bias=True)]

@@ -316,12 +316,14 @@ class ResidualCouplingLayer(nn.Module):
     def forward(self, x, x_mask, g=None, reverse=False):
         y = self.forward_cl(x.transpose(1, 2).contiguous(), None, x_mask.transpose(1, 2), g, reverse)
         if not reverse:
-            return y[0].transpose(1, 2), y[1]
+            logdet = y[1] if y[1] is not None else torch.zeros(x.size(0), dtype=x.dtype, device=x.device)     # mean-only: log-determinant 0
+            return y[0].transpose(1, 2), logdet
         return y.transpose(1, 2)
 
-    def forward_cl(self, x, lengths, mask_cl, g=None, reverse=False):
-        """x [b, t, channels] channels-last; mask_cl [b, t, 1].  pre / WN / post run on the HIP kernels."""
-        from . import wn_cl
+    def forward_cl(self, x, lengths, mask_cl, g=None, reverse=False, flip_after=False):
+        """x [b, t, channels] channels-last; mask_cl [b, t, 1].  pre / WN / post run on the HIP kernels.  flip_after: also apply
+        the modules.Flip that follows this layer in ResidualCouplingBlock (folded into the element-wise tail kernel)."""
+        from . import rowops, wn_cl
         if lengths is None:
             lengths = mask_cl[:, :, 0].sum(-1).to(torch.int32)
         half = self.half_channels
@@ -334,11 +336,16 @@ class ResidualCouplingLayer(nn.Module):
         else:
             m, logs = stats, None
         if not reverse:
+            if logs is None:
+                # mean-only (every VITS configuration): [x0, m + x1 * mask] and the flip in one launch, one more for the backward
+                return rowops.coupling_tail(x, stats, lengths, half, flip_after), None
             x1 = m + (x1 * torch.exp(logs) if logs is not None else x1) * mask_cl
             logdet = commons.sum12(logs) if logs is not None else torch.zeros(x.size(0), dtype=x.dtype, device=x.device)
-            return torch.cat([x0, x1], -1), logdet
+            out = torch.cat([x0, x1], -1)
+            return (torch.flip(out, [2]) if flip_after else out), logdet
         x1 = (x1 - m) * (torch.exp(-logs) if logs is not None else 1.0) * mask_cl
-        return torch.cat([x0, x1], -1)
+        out = torch.cat([x0, x1], -1)
+        return torch.flip(out, [2]) if flip_after else out
 
 
 class ConvFlow(nn.Module):
@@ -363,24 +370,21 @@ class ConvFlow(nn.Module):
             return out[0].transpose(1, 2), out[1]
         return out.transpose(1, 2)
 
-    def forward_cl(self, x, lengths, mask_cl, g=None, reverse=False):
-        """x [b, t, 2] float32 channels-last; g [b, t, filter_channels] (compute dtype) or None."""
+    def forward_cl(self, x, lengths, mask_cl, g=None, reverse=False, swap=False):
+        """x [b, t, 2] float32 channels-last; g [b, t, filter_channels] (compute dtype) or None.  swap: the roles of the two
+        channels are exchanged (channel 1 conditions, channel 0 is transformed) — what a physical modules.Flip in front of this
+        layer would achieve; the caller alternates it instead of flipping (and un-flipping) the state."""
         from . import rowops, wn_cl
         assert self.half_channels == 1, "the VITS duration flows transform one channel conditioned on the other"
         dtype = wn_cl.compute_dtype()
-        b, t, _ = x.shape
-        x0, x1 = x[..., :1], x[..., 1:]
-        # Conv1d(1, C, 1): the single input channel is padded to the 8-wide vector (zero weights there) so that the layer and
-        # both of its gradients run on the matrix-core kernels (the broadcast form costs two full-tensor torch reductions)
-        h = wn_cl.conv_cl(F.pad(x0, (0, 7)).to(dtype), wn_cl.weight_of(self.pre, pad_in=7), wn_cl.bias_of(self.pre), dtype=dtype)
-        h = self.convs.forward_cl(h, lengths, mask_cl, g)
+        c0, c1 = (1, 0) if swap else (0, 1)
+        # Conv1d(1, C, 1) on the conditioning channel (+ the conditioning input of the DDSConv stack) as one row kernel
+        h = rowops.flow_front(x, c0, self.pre.weight, self.pre.bias, g, dtype)
+        h = self.convs.forward_cl(h, lengths, mask_cl, None)
         n_par = self.num_bins * 3 - 1
         pad = (-n_par) % 8                                                                   # 29 -> 32 output columns
         hp = wn_cl.conv_cl(h, wn_cl.weight_of(self.proj, pad_out=pad), wn_cl.bias_of(self.proj, pad), lengths, mask_out=True, dtype=dtype)
-        y1, lad = rowops.rq_spline(x1.reshape(b * t), hp.reshape(b * t, n_par + pad), 1.0 / math.sqrt(self.filter_channels),
-                                   reverse, self.tail_bound)
-        m = mask_cl.to(x.dtype)
-        out = torch.cat([x0, y1.view(b, t, 1).to(x.dtype)], -1) * m
+        out, logdet = rowops.flow_tail(x, hp, mask_cl, 1.0 / math.sqrt(self.filter_channels), reverse, self.tail_bound, c1)
         if not reverse:
-            return out, torch.sum(lad.view(b, t) * m[..., 0], 1)
+            return out, logdet
         return out

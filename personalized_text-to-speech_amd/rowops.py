@@ -125,3 +125,125 @@ class SplineFn(torch.autograd.Function):
 
 def rq_spline(x, h, hscale, inverse, tail_bound):
     return SplineFn.apply(x, h, hscale, inverse, tail_bound)
+
+
+class FlowFrontFn(torch.autograd.Function):
+    """h = x[..., c0, None] * w + bias (+ g): the Conv1d(1, C, 1) in front of a flow's DDSConv stack with that stack's `x + g`
+    folded in (csrc/flow_edge.hip).  x [b, t, xs] float32 (xs = 1 | 2), w [C, 1, 1] / bias [C] parameters, g [b, t, C] or None."""
+
+    @staticmethod
+    def forward(ctx, x, c0, w, bias, g, dtype):
+        _lib.require_cuda(x, w)
+        xd = x.detach().float().contiguous()
+        b, t, xs = xd.shape
+        C = w.numel()
+        wd, bd = w.detach().float().reshape(C).contiguous(), (None if bias is None else bias.detach().float().contiguous())
+        gd = None if g is None else g.detach().to(dtype).contiguous()
+        h = torch.empty(b, t, C, dtype=dtype, device=xd.device)
+        rc = _lib.lib().vits_flow_front(K._DT[dtype], xd.data_ptr(), xs, c0, wd.data_ptr(), None if bd is None else bd.data_ptr(),
+                                        None if gd is None else gd.data_ptr(), h.data_ptr(), b * t, C, _lib.stream_ptr())
+        _lib.check(rc, "vits_flow_front")
+        ctx.save_for_backward(xd, wd)
+        ctx.cfg = (c0, w.shape, bias is not None, None if g is None else g.dtype, x.dtype)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        xd, wd = ctx.saved_tensors
+        c0, wshape, has_bias, g_dtype, x_dtype = ctx.cfg
+        b, t, xs = xd.shape
+        C = wd.numel()
+        dh = dh.contiguous()
+        dx = torch.empty_like(xd)
+        dw = torch.empty(C, dtype=torch.float32, device=xd.device)
+        db = torch.empty(C, dtype=torch.float32, device=xd.device)
+        L = _lib.lib()
+        nbytes = L.vits_flow_front_workspace(b * t, C)
+        ws = K.workspace(nbytes, xd.device)
+        rc = L.vits_flow_front_bwd(K._DT[dh.dtype], xd.data_ptr(), xs, c0, wd.data_ptr(), dh.data_ptr(), dx.data_ptr(), dw.data_ptr(),
+                                   db.data_ptr(), ws.data_ptr(), nbytes, b * t, C, _lib.stream_ptr())
+        _lib.check(rc, "vits_flow_front_bwd")
+        dg = None
+        if g_dtype is not None and ctx.needs_input_grad[4]:
+            dg = dh if dh.dtype == g_dtype else dh.to(g_dtype)
+        return dx.to(x_dtype), None, dw.view(wshape), (db if has_bias else None), dg, None
+
+
+def flow_front(x, c0, w, bias, g, dtype):
+    return FlowFrontFn.apply(x, int(c0), w, bias, g, dtype)
+
+
+class FlowTailFn(torch.autograd.Function):
+    """(out [b, t, 2], logdet [b]) of one ConvFlow layer given its spline parameters: channel c1 of x is transformed, the other
+    passes through, both times the mask; logdet = sum_t logabsdet * mask (modules.py:373-390) — csrc/rq_spline.hip FLOW mode."""
+
+    @staticmethod
+    def forward(ctx, x, h, mask, hscale, inverse, tail_bound, c1):
+        _lib.require_cuda(x, h, mask)
+        xd = x.detach().float().contiguous()
+        b, t, two = xd.shape
+        assert two == 2
+        hd = h.detach().reshape(b * t, -1).contiguous()
+        md = mask.detach().float().reshape(b * t).contiguous()
+        out = torch.empty_like(xd)
+        ladm = torch.empty(b, t, 1, dtype=torch.float32, device=xd.device)
+        L = _lib.lib()
+        rc = L.vits_flow_spline(K._DT[hd.dtype], xd.data_ptr(), hd.data_ptr(), hd.size(1), float(hscale), int(bool(inverse)), float(tail_bound),
+                                md.data_ptr(), int(c1), out.data_ptr(), ladm.data_ptr(), b * t, _lib.stream_ptr())
+        _lib.check(rc, "vits_flow_spline")
+        from . import reduce
+        logdet = reduce.sum12(ladm)                                   # [b] (two launches, fixed order)
+        ctx.save_for_backward(xd, hd, md)
+        ctx.cfg = (float(hscale), int(bool(inverse)), float(tail_bound), int(c1), x.dtype, h.shape)
+        return out.to(x.dtype), logdet
+
+    @staticmethod
+    def backward(ctx, dout, dlogdet):
+        xd, hd, md = ctx.saved_tensors
+        hscale, inverse, tb, c1, x_dtype, hshape = ctx.cfg
+        b, t, _ = xd.shape
+        dout = torch.zeros_like(xd) if dout is None else dout.float().contiguous()
+        dl = torch.zeros(b, dtype=torch.float32, device=xd.device) if dlogdet is None else dlogdet.float().contiguous()
+        dx = torch.empty_like(xd)
+        gh = torch.empty_like(hd)
+        rc = _lib.lib().vits_flow_spline_bwd(K._DT[hd.dtype], xd.data_ptr(), hd.data_ptr(), hd.size(1), hscale, inverse, tb, md.data_ptr(), c1,
+                                             dout.data_ptr(), dl.data_ptr(), t, dx.data_ptr(), gh.data_ptr(), b * t, _lib.stream_ptr())
+        _lib.check(rc, "vits_flow_spline_bwd")
+        return dx.to(x_dtype), gh.view(hshape), None, None, None, None, None
+
+
+def flow_tail(x, h, mask, hscale, inverse, tail_bound, c1):
+    return FlowTailFn.apply(x, h, mask, hscale, inverse, tail_bound, c1)
+
+
+class CouplingTailFn(torch.autograd.Function):
+    """flip([x0, stats + x1 * mask]) of a mean-only coupling layer and the Flip that follows it, one launch each way
+    (csrc/flow_edge.hip).  x [b, t, C], stats [b, t, C - half] (same dtype), lengths int32 [b]."""
+
+    @staticmethod
+    def forward(ctx, x, stats, lengths, half, flip):
+        _lib.require_cuda(x, stats)
+        xd, sd = x.detach().contiguous(), stats.detach().to(x.dtype).contiguous()
+        b, t, C = xd.shape
+        y = torch.empty_like(xd)
+        rc = _lib.lib().vits_coupling_tail(K._DT[xd.dtype], xd.data_ptr(), sd.data_ptr(), None if lengths is None else lengths.data_ptr(),
+                                           y.data_ptr(), b, t, C, int(half), int(bool(flip)), _lib.stream_ptr())
+        _lib.check(rc, "vits_coupling_tail")
+        ctx.lengths, ctx.cfg = lengths, (int(half), int(bool(flip)), stats.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        half, flip, sdtype = ctx.cfg
+        dy = dy.contiguous()
+        b, t, C = dy.shape
+        dx = torch.empty_like(dy)
+        ds = torch.empty(b, t, C - half, dtype=dy.dtype, device=dy.device)
+        rc = _lib.lib().vits_coupling_tail_bwd(K._DT[dy.dtype], dy.data_ptr(), None if ctx.lengths is None else ctx.lengths.data_ptr(),
+                                               dx.data_ptr(), ds.data_ptr(), b, t, C, half, flip, _lib.stream_ptr())
+        _lib.check(rc, "vits_coupling_tail_bwd")
+        return dx, (ds if ds.dtype == sdtype else ds.to(sdtype)), None, None, None
+
+
+def coupling_tail(x, stats, lengths, half, flip):
+    return CouplingTailFn.apply(x, stats, lengths, half, flip)
