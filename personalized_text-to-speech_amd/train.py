@@ -88,6 +88,7 @@ class FineTuner:
         # would run on whichever stream a gradient arrives on)
         branches = self.side_branches if (self.buckets_g.world == 1 or self.buckets_g._manual) else frozenset()
         self.net_g.side_branches = branches
+        K.WGRAD_LANE["on"] = "wgrad" in branches
 
         with self._autocast():
             y_hat, l_length, attn, ids_slice, x_mask, z_mask, (z, z_p, m_p, logs_p, m_q, logs_q) = \
