@@ -57,7 +57,7 @@ class StochasticDurationPredictor(nn.Module):
         xc = wn_cl.conv_cl(torch.detach(x).transpose(1, 2).contiguous(), wn_cl.weight_of(self.pre), wn_cl.bias_of(self.pre), dtype=dtype)
         if g is not None:
             xc = xc + self.cond(torch.detach(g)).transpose(1, 2).to(dtype)
-        xc = self.convs.forward_cl(xc, lengths, m)
+        xc = self.convs.forward_cl(xc, lengths, m, final_mask=False)             # (proj below is a masked 1x1 convolution)
         xc = wn_cl.conv_cl(xc, wn_cl.weight_of(self.proj), wn_cl.bias_of(self.proj), lengths, mask_out=True, dtype=dtype)
 
         # modules.Flip (reverse the two channels) is not executed: `swap` records the parity of the flips so far, the ConvFlow
@@ -83,7 +83,7 @@ class StochasticDurationPredictor(nn.Module):
             w_cl = w.transpose(1, 2).float()                           # [b, t, 1]
             from . import rowops
             h_w = rowops.flow_front(w_cl, 0, self.post_pre.weight, self.post_pre.bias, None, dtype)       # Conv1d(1, C, 1) on the durations
-            h_w = self.post_convs.forward_cl(h_w, lengths, m)
+            h_w = self.post_convs.forward_cl(h_w, lengths, m, final_mask=False)
             h_w = wn_cl.conv_cl(h_w, wn_cl.weight_of(self.post_proj), wn_cl.bias_of(self.post_proj), lengths, mask_out=True, dtype=dtype)
             e_q = noise.randn(w.size(0), 2, w.size(2), device=x.device, dtype=torch.float32).transpose(1, 2) * m
             z_q, logdet_tot_q = e_q, 0

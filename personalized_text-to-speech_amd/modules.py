@@ -154,10 +154,13 @@ class DDSConv(nn.Module):
                             None if g is None else g.transpose(1, 2).to(dtype))
         return y.transpose(1, 2).to(x.dtype)
 
-    def forward_cl(self, x, lengths, mask_cl, g=None):
+    def forward_cl(self, x, lengths, mask_cl, g=None, final_mask=True):
         """x [b, t, c] channels-last (compute dtype).  Per layer (modules.py:97-107): masked depth-wise
         dilated conv -> LayerNorm+GELU -> 1x1 conv (matrix cores) -> LayerNorm+GELU (+ residual when
-        dropout is off) : four launches."""
+        dropout is off) : four launches.  final_mask=False leaves the rows beyond the lengths unmasked at the output: every
+        caller in this package feeds the result to a 1x1 convolution with mask_out=True, which is row-wise — conv(x * m) * m ==
+        conv(x) * m, values and gradients — so the reference's trailing `x * x_mask` (modules.py:108) would be two wasted
+        launches each way (inside the stack the depth-wise kernels read rows beyond the lengths as zero themselves)."""
         from . import rowops, wn_cl
         if g is not None:
             x = x + g
@@ -172,7 +175,7 @@ class DDSConv(nn.Module):
                 x = x + self.drop(y)
             else:
                 x = rowops.ln_act(y, self.norms_2[i].gamma, self.norms_2[i].beta, x, self.norms_2[i].eps, 1)
-        return x * mask_cl.to(x.dtype)
+        return x * mask_cl.to(x.dtype) if final_mask else x
 
 
 class WN(nn.Module):
@@ -380,7 +383,7 @@ class ConvFlow(nn.Module):
         c0, c1 = (1, 0) if swap else (0, 1)
         # Conv1d(1, C, 1) on the conditioning channel (+ the conditioning input of the DDSConv stack) as one row kernel
         h = rowops.flow_front(x, c0, self.pre.weight, self.pre.bias, g, dtype)
-        h = self.convs.forward_cl(h, lengths, mask_cl, None)
+        h = self.convs.forward_cl(h, lengths, mask_cl, None, final_mask=False)       # (proj below is a masked 1x1 convolution)
         n_par = self.num_bins * 3 - 1
         pad = (-n_par) % 8                                                                   # 29 -> 32 output columns
         hp = wn_cl.conv_cl(h, wn_cl.weight_of(self.proj, pad_out=pad), wn_cl.bias_of(self.proj, pad), lengths, mask_out=True, dtype=dtype)
