@@ -28,8 +28,19 @@ template <typename T> __device__ __forceinline__ T from_f(float v);
 template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
 template <> __device__ __forceinline__ __bf16 from_f<__bf16>(float v) { return (__bf16)v; }
 
+// a / b as reciprocal estimate + one Newton step + one residual correction (error < 1 ulp for operands in the normal range, which
+// is all this kernel divides) instead of the v_div_scale / v_div_fmas / v_div_fixup sequence: 24 divisions per element, a third of
+// the kernel's instructions.  (Tried first as a cure for the kernel's irreproducibility next to other streams' kernels — it is
+// not: see the Makefile's FLAGS_rq_spline and DESIGN.md §6b.)
+__device__ __forceinline__ float fdiv(float a, float b) {
+  float r = __builtin_amdgcn_rcpf(b);
+  r = fmaf(fmaf(-b, r, 1.0f), r, r);
+  const float q = a * r;
+  return fmaf(fmaf(-b, q, a), r, q);
+}
+
 __device__ __forceinline__ float softplus_f(float v) { return v > 20.f ? v : log1pf(expf(v)); }
-__device__ __forceinline__ float sigmoid_f(float v) { return 1.f / (1.f + expf(-v)); }
+__device__ __forceinline__ float sigmoid_f(float v) { return fdiv(1.f, 1.f + expf(-v)); }
 
 struct Knots {
   float p[NB];        // softmax probabilities
@@ -43,7 +54,7 @@ __device__ __forceinline__ void make_knots(const float* u, float B, Knots& k) {
   float s = 0.f;
 #pragma unroll
   for (int j = 0; j < NB; ++j) { k.p[j] = expf(u[j] - m); s += k.p[j]; }
-  const float inv = 1.f / s;
+  const float inv = fdiv(1.f, s);
   float cum = 0.f;
   k.c[0] = -B;
 #pragma unroll
@@ -126,13 +137,13 @@ __global__ void spline_kernel(const float* __restrict__ x, const TH* __restrict_
   const float W = CW1 - CW, Hh = CH1 - CH;
   const float d0 = (i == 0) ? d_edge : kMin + softplus_f(ud0);
   const float d1 = (i == NB - 1) ? d_edge : kMin + softplus_f(ud1);
-  const float delta = Hh / W;
+  const float delta = fdiv(Hh, W);
   const float s = d0 + d1 - 2.f * delta;
 
   float theta, out;
   float a = 0.f, b = 0.f, c = 0.f, sd = 0.f, D = 0.f, u = 0.f;
   if (!inverse) {
-    theta = (xv - CW) / W;
+    theta = fdiv(xv - CW, W);
   } else {
     u = xv - CH;
     a = u * s + Hh * (delta - d0);
@@ -140,7 +151,7 @@ __global__ void spline_kernel(const float* __restrict__ x, const TH* __restrict_
     c = -delta * u;
     sd = sqrtf(b * b - 4.f * a * c);
     D = -b - sd;
-    theta = 2.f * c / D;
+    theta = fdiv(2.f * c, D);
   }
   const float q = theta * (1.f - theta);
   const float den = delta + s * q;
@@ -148,7 +159,7 @@ __global__ void spline_kernel(const float* __restrict__ x, const TH* __restrict_
   const float dnum = delta * delta * E;
   const float num = Hh * (delta * theta * theta + d0 * q);
   const float l = logf(dnum) - 2.f * logf(den);
-  if (!inverse) out = CH + num / den; else out = theta * W + CW;
+  if (!inverse) out = CH + fdiv(num, den); else out = theta * W + CW;
   if (!BWD) {
     y[ix] = out * mv;
     lad[e] = (inverse ? -l : l) * mv;
@@ -161,9 +172,9 @@ __global__ void spline_kernel(const float* __restrict__ x, const TH* __restrict_
   float g_x = 0.f;
   float g_dnum, g_den;
   if (!inverse) {
-    const float g_num = gyv / den;
-    g_den = -gyv * num / (den * den) - 2.f * glv / den;
-    g_dnum = glv / dnum;
+    const float g_num = fdiv(gyv, den);
+    g_den = -fdiv(gyv * num, den * den) - fdiv(2.f * glv, den);
+    g_dnum = fdiv(glv, dnum);
     g_CH += gyv;
     g_H += g_num * (delta * theta * theta + d0 * q);
     g_delta += g_num * Hh * theta * theta;
@@ -174,8 +185,8 @@ __global__ void spline_kernel(const float* __restrict__ x, const TH* __restrict_
     g_theta += gyv * W;
     g_W += gyv * theta;
     g_CW += gyv;
-    g_dnum = -glv / dnum;
-    g_den = 2.f * glv / den;
+    g_dnum = -fdiv(glv, dnum);
+    g_den = fdiv(2.f * glv, den);
   }
   // den = delta + s q
   g_delta += g_den; g_s += g_den * q; g_q += g_den * s;
@@ -190,15 +201,15 @@ __global__ void spline_kernel(const float* __restrict__ x, const TH* __restrict_
   // q = theta (1 - theta)
   g_theta += g_q * (1.f - 2.f * theta);
   if (!inverse) {
-    g_x = g_theta / W;
-    g_CW -= g_theta / W;
-    g_W -= g_theta * theta / W;
+    g_x = fdiv(g_theta, W);
+    g_CW -= fdiv(g_theta, W);
+    g_W -= fdiv(g_theta * theta, W);
   } else {
     // theta = 2c / D, D = -b - sqrt(b^2 - 4ac)
-    float g_c = g_theta * 2.f / D;
-    const float g_D = -g_theta * theta / D;
+    float g_c = fdiv(g_theta * 2.f, D);
+    const float g_D = -fdiv(g_theta * theta, D);
     float g_b = -g_D;
-    const float g_disc = -g_D / (2.f * sd);
+    const float g_disc = -fdiv(g_D, 2.f * sd);
     g_b += g_disc * 2.f * b;
     const float g_a = -4.f * c * g_disc;
     g_c += -4.f * a * g_disc;
@@ -211,8 +222,8 @@ __global__ void spline_kernel(const float* __restrict__ x, const TH* __restrict_
   }
   // s = d0 + d1 - 2 delta ; delta = H / W
   g_d0 += g_s; g_d1 += g_s; g_delta -= 2.f * g_s;
-  g_H += g_delta / W;
-  g_W -= g_delta * Hh / (W * W);
+  g_H += fdiv(g_delta, W);
+  g_W -= fdiv(g_delta * Hh, W * W);
   // W = CW1 - CW, H = CH1 - CH
   float g_uw[NB], g_uh[NB];
   knots_bwd(kw, i, g_CW - g_W, g_W, B, g_uw);

@@ -471,7 +471,7 @@ class SynthesizerTrn(nn.Module):
         self.resblock, self.resblock_kernel_sizes, self.resblock_dilation_sizes = resblock, resblock_kernel_sizes, resblock_dilation_sizes
         self.upsample_rates, self.upsample_initial_channel, self.upsample_kernel_sizes = upsample_rates, upsample_initial_channel, upsample_kernel_sizes
         self.segment_size, self.n_speakers, self.gin_channels, self.use_sdp = segment_size, n_speakers, gin_channels, use_sdp
-        self.side_branches = {"enc_p"}      # training forward: sub-graphs that run as side-stream branches (kernels.SideBranch)
+        self.side_branches = {"enc_p", "dp"}      # training forward: sub-graphs that run as side-stream branches (kernels.SideBranch)
 
         self.enc_p = TextEncoder(n_vocab, inter_channels, hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout)
         self.dec = Generator(inter_channels, resblock, resblock_kernel_sizes, resblock_dilation_sizes, upsample_rates,

@@ -46,13 +46,11 @@ class FineTuner:
         self.optim_d = FlatAdamW(self.net_d.parameters(), hps.train.learning_rate,
                                  runs=[weight_arena.param_order(MultiPeriodDiscriminator._arena_specs(self.net_d))], **kw)
         self._graph = None
-        # Sub-graphs run as side-stream branches (kernels.SideBranch).  "enc_p": the text encoder next to the posterior encoder +
-        # flow, forward and backward (-2.5 ms/step, replays bitwise reproducible).  Also available, OFF by default: "dp" (the
-        # stochastic duration predictor next to the decoder / discriminators: a further -2.6 ms, but in ~20 % of the replays the
-        # gradients of ONE of its ConvFlow layers come out ~1 % different — a race that was not found; ruled out: deferred slab
-        # reductions, shared scratch buffers, uninitialised global reads, the cross-stream gradient hand-off — DESIGN.md §6b) and
-        # "mel" (the mel of the generated waveform next to the discriminators: slower, 36.6 vs 34.5 ms).
-        self.side_branches = frozenset(("enc_p",))
+        # Sub-graphs run as side-stream branches (kernels.SideBranch): "enc_p" = the text encoder next to the posterior encoder +
+        # flow, "dp" = the stochastic duration predictor next to the decoder / discriminators, forward and backward
+        # (34.5 -> 27.3 ms/step together; replays bitwise reproducible — DESIGN.md §6b tells how the "dp" branch exposed the
+        # spline kernel's irreproducibility under concurrency and what cured it).  Also available, off: "mel", "wgrad" (slower).
+        self.side_branches = frozenset(("enc_p", "dp"))
         self.buckets_g = GradBuckets(self.net_g.parameters(), bucket_bytes)
         self.buckets_d = GradBuckets(self.net_d.parameters(), bucket_bytes)
         self.sched_g = torch.optim.lr_scheduler.ExponentialLR(self.optim_g, gamma=hps.train.lr_decay)
