@@ -535,53 +535,10 @@ def tile_counters(device):
     return buf
 
 
-# Weight gradients whose result goes into a weight arena are read by nobody until that arena's PrepFn.backward: with
-# WGRAD_LANE["on"] they are launched on a side stream that only ever WAITS for the main one (one dependency edge per launch in a
-# captured graph, no join until the arena's backward), so the main stream's chain of data gradients does not queue behind them.
-# Callers whose dy / x buffers are rewritten in place afterwards (wn_cl.WNFn) pass lane=False.
-WGRAD_LANE = {"on": False}
-_lane_state = {}           # device index -> [stream, collector, used since the last join]
-
-
-def _wgrad_lane(device):
-    st = _lane_state.get(device.index)
-    if st is None:
-        stream = torch.cuda.Stream(device)
-        with torch.cuda.stream(stream):
-            st = _lane_state[device.index] = [stream, DeferredReductions(device), False]
-    return st
-
-
-def wgrad_lane_join(device):
-    """Second stages of the lane's launches (on the lane), then the current stream waits for the lane."""
-    st = _lane_state.get(torch.device(device).index)
-    if st is None or not st[2]:
-        return
-    cur = torch.cuda.current_stream(device)
-    with torch.cuda.stream(st[0]):
-        st[1].flush()
-    cur.wait_stream(st[0])
-    st[2] = False
-
-
-def conv1d_cl_wgrad_raw(x, dy, k, lengths=None, dil=1, pad=0, stride=1, in_slope=1.0, flags=0, out=None, dbias=None, groups=1, defer=None,
-                        lane=True):
+def conv1d_cl_wgrad_raw(x, dy, k, lengths=None, dil=1, pad=0, stride=1, in_slope=1.0, flags=0, out=None, dbias=None, groups=1, defer=None):
     """dW [k, c_out, c_in] float32 of conv1d_cl_raw(x, w, ...) given dy [b, t_out, c_out]; optionally the bias
     gradient (column sums of dy) into `dbias` float32 [c_out] in the same launch."""
     _lib.require_cuda(x, dy)
-    if lane and WGRAD_LANE["on"] and out is not None:
-        from . import weight_arena
-        if weight_arena.owns_dw(out):
-            st = _wgrad_lane(x.device)
-            main = torch.cuda.current_stream(x.device)
-            if main.cuda_stream != st[0].cuda_stream:
-                st[0].wait_stream(main)
-                for t in (x, dy, lengths, dbias):
-                    if t is not None:
-                        t.record_stream(st[0])
-                st[2] = True
-                with torch.cuda.stream(st[0]):
-                    return conv1d_cl_wgrad_raw(x, dy, k, lengths, dil, pad, stride, in_slope, flags, out, dbias, groups, st[1], lane=False)
     assert x.dtype == dy.dtype
     b, t, c_in = x.shape
     c_out = dy.shape[2]

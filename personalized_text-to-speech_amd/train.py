@@ -49,7 +49,7 @@ class FineTuner:
         # Sub-graphs run as side-stream branches (kernels.SideBranch): "enc_p" = the text encoder next to the posterior encoder +
         # flow, "dp" = the stochastic duration predictor next to the decoder / discriminators, forward and backward
         # (34.5 -> 27.3 ms/step together; replays bitwise reproducible — DESIGN.md §6b tells how the "dp" branch exposed the
-        # spline kernel's irreproducibility under concurrency and what cured it).  Also available, off: "mel", "wgrad" (slower).
+        # spline kernel's irreproducibility under concurrency and what cured it).  Also available, off: "mel" (slower).
         self.side_branches = frozenset(("enc_p", "dp"))
         self.buckets_g = GradBuckets(self.net_g.parameters(), bucket_bytes)
         self.buckets_d = GradBuckets(self.net_d.parameters(), bucket_bytes)
@@ -86,7 +86,6 @@ class FineTuner:
         # would run on whichever stream a gradient arrives on)
         branches = self.side_branches if (self.buckets_g.world == 1 or self.buckets_g._manual) else frozenset()
         self.net_g.side_branches = branches
-        K.WGRAD_LANE["on"] = "wgrad" in branches
 
         with self._autocast():
             y_hat, l_length, attn, ids_slice, x_mask, z_mask, (z, z_p, m_p, logs_p, m_q, logs_q) = \

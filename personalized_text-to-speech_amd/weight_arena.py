@@ -21,7 +21,6 @@ from . import _lib
 
 _DT = {torch.float32: 0, torch.bfloat16: 2}
 _current = None            # dict (id(module), part) -> handle tensor, valid inside a scope
-_dw_storages = set()       # storage addresses of every arena's weight-gradient buffer (kernels.conv1d_cl_wgrad_raw asks owns_dw())
 _registry = {}             # handle.data_ptr() -> (arena, index)
 _bias_registry = {}        # bias handle.data_ptr() -> (arena, bias index)
 
@@ -114,8 +113,6 @@ class WeightArena:
         self.w_bwd = torch.zeros(off, dtype=dtype, device=dev)
         self.handle = self.w_fwd if dtype == torch.float32 else torch.empty(off, dtype=torch.float32, device=dev)
         self.dw = torch.zeros(off, dtype=torch.float32, device=dev)
-        if self.dw.is_cuda:
-            _dw_storages.add(self.dw.untyped_storage().data_ptr())
         view = lambda buf, o, s, shape: buf[o:o + s.numel].view(shape)
         self.fwd = [view(self.w_fwd, o, s, s.fwd_shape) for o, s in zip(offs, specs)]
         self.bwd = [view(self.w_bwd, o, s, s.bwd_shape) for o, s in zip(offs, specs)]
@@ -218,9 +215,6 @@ class PrepFn(torch.autograd.Function):
                 "weight_arena: this backward belongs to forward #%d, but forward #%d has since overwritten the arena's shared "
                 "operands and gradient buffers (two forwards of one network before a backward, e.g. loss(net(a)) + loss(net(b))): "
                 "run each forward's backward before the next forward, or batch the inputs" % (ctx.gen, arena.gen))
-        if arena.w_fwd.is_cuda:
-            from . import kernels
-            kernels.wgrad_lane_join(arena.w_fwd.device)   # weight-gradient launches that ran on the side lane (kernels.WGRAD_LANE)
         arena.flush_deferred()                       # the deferred second stages of this network's weight-gradient launches
         arena.claimed.clear()
         # gradient accumulation (no zero_grad between two backwards): a param.grad that still aliases `dparam` would be
@@ -272,11 +266,6 @@ class Resolved:
 
 
 _constants = {}            # data_ptr -> Resolved, for constant operands registered with register_constant()
-
-
-def owns_dw(t):
-    """True if `t` is (a view of) an arena's weight-gradient buffer: its content is only read by PrepFn.backward."""
-    return t is not None and t.is_cuda and t.untyped_storage().data_ptr() in _dw_storages
 
 
 def register_constant(w_fwd):

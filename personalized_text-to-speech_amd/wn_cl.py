@@ -224,11 +224,11 @@ class WNFn(torch.autograd.Function):
             last = i == L - 1
             dy_rs = d_o if last else dcat
             db_rs = torch.empty(H if last else 2 * H, dtype=torch.float32, device=d_out.device)
-            grads[4 * i + 2] = WG(acts, dy_rs, 1, out=r_rs.claim_dw(ctx), dbias=db_rs, defer=defer, lane=False)      # (dcat is rewritten in place below)
+            grads[4 * i + 2] = WG(acts, dy_rs, 1, out=r_rs.claim_dw(ctx), dbias=db_rs, defer=defer)
             grads[4 * i + 3] = db_rs
             d_pre = C(dy_rs, WA.bwd_operand(r_rs), None, mg_src=pre, lengths=lengths, flags=K.CONV_GATE_BWD | K.CONV_MASK_OUT, gate_h=H)
             db_in = torch.empty(2 * H, dtype=torch.float32, device=d_out.device)
-            grads[4 * i] = WG(h, d_pre, k, dil=d, pad=pad, out=r_in.claim_dw(ctx), dbias=db_in, defer=defer, lane=False)
+            grads[4 * i] = WG(h, d_pre, k, dil=d, pad=pad, out=r_in.claim_dw(ctx), dbias=db_in, defer=defer)
             grads[4 * i + 1] = db_in
             if dcond is not None:
                 dcond.append(K.colsum(d_pre, per_item=True))              # [b, 2H]: gradient of cond[i]

@@ -81,7 +81,7 @@ def conv1d_cl_raw(x, w, bias=None, bias_b=None, res=None, mg_src=None, out=None,
     return v
 
 
-def conv1d_cl_wgrad_raw(x, dy, k, lengths=None, dil=1, pad=0, stride=1, in_slope=1.0, flags=0, out=None, dbias=None, groups=1, defer=None, lane=True):
+def conv1d_cl_wgrad_raw(x, dy, k, lengths=None, dil=1, pad=0, stride=1, in_slope=1.0, flags=0, out=None, dbias=None, groups=1, defer=None):
     b, t, c_in = x.shape
     c_out = dy.shape[2]
     w = torch.zeros(k, c_out, c_in, device=x.device, requires_grad=True)
