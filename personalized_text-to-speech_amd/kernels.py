@@ -411,13 +411,15 @@ class SideBranch:
         return False
 
     def join(self, *outputs):
-        """The main stream waits for the branch.  Returns the outputs wrapped so that, in the backward pass, the gradient that
-        re-enters the branch is first copied into memory that belongs to the SIDE stream (see _HandOff)."""
-        self.main.wait_stream(self.side)
+        """The CURRENT stream (the one the branch was forked from, or another branch that consumes its results) waits for the
+        branch.  Returns the outputs wrapped so that, in the backward pass, the gradient that re-enters the branch is first
+        copied into memory that belongs to the side stream (see _HandOff)."""
+        cur = torch.cuda.current_stream(self.side.device)
+        cur.wait_stream(self.side)
         res = []
         for t in outputs:
             if torch.is_tensor(t):
-                t.record_stream(self.main)
+                t.record_stream(cur)
                 if t.requires_grad:
                     t = _HandOff.apply(t, self.side)
             res.append(t)
