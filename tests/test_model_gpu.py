@@ -146,9 +146,12 @@ def test_captured_step_replays_reproducibly(pkg):
     hps = cfgs.get("modified_finetune_speaker")
     ft = tr.FineTuner(hps, "cuda:0", amp=True)
     batch = tr.synthetic_batch(hps, 4, (100, 160), "cuda:0")
+    assert ft.side_branches == {"enc_p", "dp"}       # text encoder and duration predictor as side-stream branches of the graph
     ft.capture(batch, warmup=2)
-    losses = ft.verify_replay()
-    assert all(np.isfinite(list(losses.values())))
+    for _ in range(3):                                # a race between branches would be intermittent
+        losses = ft.verify_replay()
+        assert all(np.isfinite(list(losses.values())))
+        assert max(ft.replay_vs_eager.values()) <= 1e-6, ft.replay_vs_eager
     for _ in range(3):
         out = ft.replay()
     assert all(np.isfinite([float(v) for v in out.values()]))
