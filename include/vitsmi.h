@@ -417,6 +417,20 @@ int vits_coupling_tail(int dtype, const void* x, const void* stats, const int32_
                        void* stream);
 int vits_coupling_tail_bwd(int dtype, const void* dy, const int32_t* lengths, void* dx, void* dstats, int b, int t, int c, int half, int flip,
                            void* stream);
+/* modules.ElementwiseAffine (modules.py:280-295) on a channels-last float32 [b][t][c] state (c <= 8; swap: parameters indexed as if
+ * the channels were flipped): y = (m + exp(logs) x) mask, logdet[b] = sum(logs) len[b]; inverse = 1: y = (x - m) exp(-logs) mask
+ * (logdet may be NULL).  Backward (forward direction): dx, dm[c], dlogs[c] from dy and dlogdet (either may be NULL = zero). */
+int vits_flow_affine(const float* x, const float* m, const float* logs, const int32_t* lengths, float* y, float* logdet, int b, int t, int c,
+                     int swap, int inverse, void* stream);
+int vits_flow_affine_bwd(const float* x, const float* logs, const int32_t* lengths, const float* dy, const float* dlogdet, float* dx, float* dm,
+                         float* dlogs, int b, int t, int c, int swap, void* stream);
+/* The variational-dequantisation step between the two flow chains of StochasticDurationPredictor.forward (models.py:71-80) with
+ * modules.Log (modules.py:259-267): zq [b][t][2] = [z_u, z1], w [b][t] durations ->
+ *   out [b][t][2] = [log(clamp_min((w - sigmoid(z_u) m) m, 1e-5)) m, z1],  s1[b] = sum_t (logsigmoid(z_u) + logsigmoid(-z_u)) m,
+ *   s2[b] = sum_t -out[..., 0];  backward: dzq from dout, ds1, ds2 (each may be NULL = zero). */
+int vits_flow_dequant_log(const float* zq, const float* w, const int32_t* lengths, float* out, float* s1, float* s2, int b, int t, void* stream);
+int vits_flow_dequant_log_bwd(const float* zq, const float* w, const int32_t* lengths, const float* dout, const float* ds1, const float* ds2,
+                              float* dzq, int b, int t, void* stream);
 int vits_flow_front(int dtype, const float* x, int xs, int c0, const float* w, const float* bias, const void* g, void* h, int rows,
                     int c, void* stream);
 size_t vits_flow_front_workspace(int rows, int c);

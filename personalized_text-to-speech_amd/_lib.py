@@ -63,6 +63,10 @@ SIGNATURES = {
     "vits_gradnorm_final": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_int, c_void_p]),
     "vits_coupling_tail": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
     "vits_coupling_tail_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
+    "vits_flow_affine": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p]),
+    "vits_flow_affine_bwd": (c_int, [c_void_p] * 8 + [c_int] * 4 + [c_void_p]),
+    "vits_flow_dequant_log": (c_int, [c_void_p] * 6 + [c_int, c_int, c_void_p]),
+    "vits_flow_dequant_log_bwd": (c_int, [c_void_p] * 7 + [c_int, c_int, c_void_p]),
     "vits_flow_front": (c_int, [c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "vits_flow_front_workspace": (c_size_t, [c_int, c_int]),
     "vits_flow_front_bwd": (c_int, [c_int, c_void_p, c_int, c_int] + [c_void_p] * 6 + [c_size_t, c_int, c_int, c_void_p]),

@@ -124,6 +124,116 @@ __global__ __launch_bounds__(kThreads) void coupling_tail_kernel(const T* __rest
   }
 }
 
+// ---- modules.ElementwiseAffine (modules.py:280-295) on a channels-last [b][t][C] state, C <= 8 ------------------------------------
+// forward: y = (m[pc] + exp(logs[pc]) x) mask, logdet[b] = (sum_c logs[c]) len[b];  inverse: y = (x - m[pc]) exp(-logs[pc]) mask
+// (pc = C-1-c when `swap`: the state is virtually flipped, see vits_flow_spline).
+__global__ __launch_bounds__(kThreads) void affine_fwd_kernel(const float* __restrict__ x, const float* __restrict__ m, const float* __restrict__ logs,
+                                                              const int* __restrict__ lengths, float* __restrict__ y, float* __restrict__ logdet,
+                                                              int B, int t, int C, int swap, int inverse) {
+  const size_t n = (size_t)B * t * C;
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (size_t)gridDim.x * kThreads) {
+    const size_t r = i / C;
+    const int c = (int)(i - r * C), pc = swap ? C - 1 - c : c;
+    const int b = (int)(r / t), tt = (int)(r - (size_t)b * t);
+    const float mv = tt < lengths[b] ? 1.f : 0.f;
+    y[i] = inverse ? (x[i] - m[pc]) * expf(-logs[pc]) * mv : (m[pc] + expf(logs[pc]) * x[i]) * mv;
+  }
+  if (logdet && blockIdx.x == 0 && (int)threadIdx.x < B) {
+    float sl = 0.f;
+    for (int c = 0; c < C; ++c) sl += logs[c];
+    const int len = lengths[threadIdx.x] < t ? lengths[threadIdx.x] : t;
+    logdet[threadIdx.x] = sl * (float)len;
+  }
+}
+
+// one workgroup: dx = dy exp(logs) mask;  dm[pc] = sum dy mask;  dlogs[pc] = sum dy exp(logs) x mask + sum_b dlogdet[b] len[b]
+__global__ __launch_bounds__(kThreads) void affine_bwd_kernel(const float* __restrict__ x, const float* __restrict__ logs, const int* __restrict__ lengths,
+                                                              const float* __restrict__ dy, const float* __restrict__ dlogdet, float* __restrict__ dx,
+                                                              float* __restrict__ dm, float* __restrict__ dlogs, int B, int t, int C, int swap) {
+  __shared__ float red[kThreads][16];
+  float am[8], al[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) { am[c] = 0.f; al[c] = 0.f; }
+  const size_t rows = (size_t)B * t;
+  for (size_t r = threadIdx.x; r < rows; r += kThreads) {
+    const int b = (int)(r / t), tt = (int)(r - (size_t)b * t);
+    const float mv = tt < lengths[b] ? 1.f : 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      if (c < C) {
+        const int pc = swap ? C - 1 - c : c;
+        const float d = (dy ? dy[r * C + c] : 0.f) * mv, e = expf(logs[pc]);
+        dx[r * C + c] = d * e;
+        am[c] += d;
+        al[c] += d * e * x[r * C + c];
+      }
+  }
+#pragma unroll
+  for (int c = 0; c < 8; ++c) { red[threadIdx.x][c] = am[c]; red[threadIdx.x][8 + c] = al[c]; }
+  __syncthreads();
+  if ((int)threadIdx.x < 2 * C) {
+    const int c = threadIdx.x % C, which = threadIdx.x / C;
+    float s = 0.f;
+    for (int k = 0; k < kThreads; ++k) s += red[k][which * 8 + c];
+    const int pc = swap ? C - 1 - c : c;
+    if (which == 0) dm[pc] = s;
+    else {
+      float ld = 0.f;
+      if (dlogdet)
+        for (int b = 0; b < B; ++b) ld += dlogdet[b] * (float)(lengths[b] < t ? lengths[b] : t);
+      dlogs[pc] = s + ld;
+    }
+  }
+}
+
+// ---- the dequantisation + Log step between the two flow chains of the stochastic duration predictor (models.py:71-80) ---------
+//   u = sigmoid(z_u) m;  z0 = (w - u) m;  s1[b] = sum_t (logsigmoid(z_u) + logsigmoid(-z_u)) m
+//   z0l = log(max(z0, 1e-5)) m  (modules.Log);  s2[b] = sum_t -z0l;   out[r] = [z0l, z1]            (z_q [rows][2] = [z_u, z1])
+// one workgroup per item (the per-item sums are its block reductions, fixed order)
+__device__ __forceinline__ float logsigmoid_f(float v) { return fminf(v, 0.f) - log1pf(expf(-fabsf(v))); }
+
+template <bool BWD>
+__global__ __launch_bounds__(kThreads) void dequant_log_kernel(const float* __restrict__ zq, const float* __restrict__ w, const int* __restrict__ lengths,
+                                                               float* __restrict__ out, float* __restrict__ s1, float* __restrict__ s2,
+                                                               const float* __restrict__ dout, const float* __restrict__ ds1, const float* __restrict__ ds2,
+                                                               float* __restrict__ dzq, int t) {
+  __shared__ float red[2][4];
+  const int b = blockIdx.x, len = lengths[b] < t ? lengths[b] : t;
+  float a1 = 0.f, a2 = 0.f;
+  const float g1 = BWD && ds1 ? ds1[b] : 0.f, g2 = BWD && ds2 ? ds2[b] : 0.f;
+  for (int tt = threadIdx.x; tt < t; tt += kThreads) {
+    const size_t r = (size_t)b * t + tt;
+    const float mv = tt < len ? 1.f : 0.f;
+    const float zu = zq[2 * r], z1 = zq[2 * r + 1];
+    const float sg = 1.f / (1.f + expf(-zu));
+    const float z0 = (w[r] - sg * mv) * mv;
+    const bool above = z0 > 1e-5f;
+    const float z0l = logf(above ? z0 : 1e-5f) * mv;
+    if (!BWD) {
+      out[2 * r] = z0l; out[2 * r + 1] = z1;
+      a1 += (logsigmoid_f(zu) + logsigmoid_f(-zu)) * mv;
+      a2 -= z0l;
+    } else {
+      const float d0 = (dout ? dout[2 * r] : 0.f) - g2;              // gradient of z0l (its direct use and the -z0l sum)
+      const float dz0 = above ? d0 * mv / z0 : 0.f;                    // log(clamp_min(z0, 1e-5)): no gradient below the clamp
+      const float du = -dz0 * mv;                                      // z0 = (w - u) m
+      dzq[2 * r] = du * mv * sg * (1.f - sg) + g1 * mv * (1.f - 2.f * sg);
+      dzq[2 * r + 1] = dout ? dout[2 * r + 1] : 0.f;
+    }
+  }
+  if (!BWD) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = a1; red[1][wave] = a2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      s1[b] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+      s2[b] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+  }
+}
+
 int front_wgs(int rows) { int w = (rows + 31) / 32; return w < 1 ? 1 : (w > 128 ? 128 : w); }
 
 }  // namespace
@@ -193,4 +303,41 @@ extern "C" int vits_coupling_tail_bwd(int dtype, const void* dy, const int32_t* 
     hipLaunchKernelGGL((coupling_tail_kernel<float, true>), dim3(blocks), dim3(kThreads), 0, s, (const float*)dy, (const float*)nullptr, lengths, (float*)dx, (float*)dstats, t, c, half, flip, n);
   else return VITS_E_UNSUPPORTED;
   return vits::check_launch("vits_coupling_tail_bwd");
+}
+
+extern "C" int vits_flow_affine(const float* x, const float* m, const float* logs, const int32_t* lengths, float* y, float* logdet, int b, int t,
+                                int c, int swap, int inverse, void* stream) {
+  if (!x || !m || !logs || !lengths || !y || b <= 0 || t <= 0 || c <= 0) return VITS_E_BADARG;
+  if (c > 8 || b > kThreads) return VITS_E_UNSUPPORTED;
+  const size_t n = (size_t)b * t * c;
+  unsigned blocks = (unsigned)((n + kThreads * 4 - 1) / (kThreads * 4));
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(affine_fwd_kernel, dim3(blocks), dim3(kThreads), 0, static_cast<hipStream_t>(stream), x, m, logs, lengths, y, logdet, b, t, c, swap,
+                     inverse);
+  return vits::check_launch("vits_flow_affine");
+}
+
+extern "C" int vits_flow_affine_bwd(const float* x, const float* logs, const int32_t* lengths, const float* dy, const float* dlogdet, float* dx,
+                                    float* dm, float* dlogs, int b, int t, int c, int swap, void* stream) {
+  if (!x || !logs || !lengths || !dx || !dm || !dlogs || b <= 0 || t <= 0 || c <= 0) return VITS_E_BADARG;
+  if (c > 8) return VITS_E_UNSUPPORTED;
+  hipLaunchKernelGGL(affine_bwd_kernel, dim3(1), dim3(kThreads), 0, static_cast<hipStream_t>(stream), x, logs, lengths, dy, dlogdet, dx, dm, dlogs, b, t,
+                     c, swap);
+  return vits::check_launch("vits_flow_affine_bwd");
+}
+
+extern "C" int vits_flow_dequant_log(const float* zq, const float* w, const int32_t* lengths, float* out, float* s1, float* s2, int b, int t,
+                                     void* stream) {
+  if (!zq || !w || !lengths || !out || !s1 || !s2 || b <= 0 || t <= 0) return VITS_E_BADARG;
+  hipLaunchKernelGGL(dequant_log_kernel<false>, dim3(b), dim3(kThreads), 0, static_cast<hipStream_t>(stream), zq, w, lengths, out, s1, s2, nullptr, nullptr,
+                     nullptr, nullptr, t);
+  return vits::check_launch("vits_flow_dequant_log");
+}
+
+extern "C" int vits_flow_dequant_log_bwd(const float* zq, const float* w, const int32_t* lengths, const float* dout, const float* ds1, const float* ds2,
+                                         float* dzq, int b, int t, void* stream) {
+  if (!zq || !w || !lengths || !dzq || b <= 0 || t <= 0) return VITS_E_BADARG;
+  hipLaunchKernelGGL(dequant_log_kernel<true>, dim3(b), dim3(kThreads), 0, static_cast<hipStream_t>(stream), zq, w, lengths, nullptr, nullptr, nullptr, dout,
+                     ds1, ds2, dzq, t);
+  return vits::check_launch("vits_flow_dequant_log_bwd");
 }

@@ -69,12 +69,8 @@ class StochasticDurationPredictor(nn.Module):
                 state["swap"] = not state["swap"]
                 return z, None
             if isinstance(flow, modules.ElementwiseAffine):
-                mm, ls = flow.m.view(1, 1, -1), flow.logs.view(1, 1, -1)
-                if state["swap"]:
-                    mm, ls = mm.flip(-1), ls.flip(-1)
-                if not reverse:
-                    return (mm + torch.exp(ls) * z) * m, commons.sum12(ls * m)
-                return (z - mm) * torch.exp(-ls) * m, None
+                from . import rowops
+                return rowops.flow_affine(z, flow.m, flow.logs, lengths, state["swap"], reverse)       # (y, logdet | None)
             out = flow.forward_cl(z, lengths, m, cond, reverse, swap=state["swap"])
             return (out[0], out[1]) if not reverse else (out, None)
 
@@ -93,15 +89,10 @@ class StochasticDurationPredictor(nn.Module):
                 if ld is not None:
                     logdet_tot_q = logdet_tot_q + ld
             assert not state["swap"]                                   # an even number of flips: natural channel order
-            z_u, z1 = z_q[..., :1], z_q[..., 1:]
-            u = torch.sigmoid(z_u) * m
-            z0 = (w_cl - u) * m
-            logdet_tot_q = logdet_tot_q + commons.sum12((F.logsigmoid(z_u) + F.logsigmoid(-z_u)) * m)
+            # u = sigmoid(z_u) m, z0 = (w - u) m, its log-determinant term, modules.Log on z0 and cat([z0, z1]): one kernel each way
+            z, ld_u, logdet_tot = rowops.dequant_log(z_q, w_cl, lengths)
+            logdet_tot_q = logdet_tot_q + ld_u
             logq = commons.sum12(-0.5 * (commons.LOG_2PI + (e_q ** 2)) * m) - logdet_tot_q
-
-            z0 = torch.log(torch.clamp_min(z0, 1e-5)) * m             # modules.Log
-            logdet_tot = commons.sum12(-z0)
-            z = torch.cat([z0, z1], -1)
             for flow in self.flows:
                 z, ld = run(flow, z, xc)
                 if ld is not None:

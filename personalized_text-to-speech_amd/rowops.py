@@ -247,3 +247,85 @@ class CouplingTailFn(torch.autograd.Function):
 
 def coupling_tail(x, stats, lengths, half, flip):
     return CouplingTailFn.apply(x, stats, lengths, half, flip)
+
+
+class FlowAffineFn(torch.autograd.Function):
+    """modules.ElementwiseAffine on a channels-last float32 state [b, t, C] (csrc/flow_edge.hip): forward -> (y, logdet [b]),
+    inverse -> (y, None).  m / logs: the module's [C, 1] parameters; swap: indexed as if the channels were flipped."""
+
+    @staticmethod
+    def forward(ctx, x, m, logs, lengths, swap, inverse):
+        _lib.require_cuda(x, m, logs, lengths)
+        xd = x.detach().float().contiguous()
+        b, t, C = xd.shape
+        md, ld = m.detach().float().reshape(C).contiguous(), logs.detach().float().reshape(C).contiguous()
+        y = torch.empty_like(xd)
+        logdet = None if inverse else torch.empty(b, dtype=torch.float32, device=xd.device)
+        rc = _lib.lib().vits_flow_affine(xd.data_ptr(), md.data_ptr(), ld.data_ptr(), lengths.data_ptr(), y.data_ptr(),
+                                         None if logdet is None else logdet.data_ptr(), b, t, C, int(bool(swap)), int(bool(inverse)), _lib.stream_ptr())
+        _lib.check(rc, "vits_flow_affine")
+        ctx.save_for_backward(xd, ld, lengths)
+        ctx.cfg = (int(bool(swap)), bool(inverse), m.shape, x.dtype)
+        if inverse:
+            ctx.mark_non_differentiable(y)
+            return y.to(x.dtype), None
+        return y.to(x.dtype), logdet
+
+    @staticmethod
+    def backward(ctx, dy, dlogdet):
+        xd, ld, lengths = ctx.saved_tensors
+        swap, inverse, pshape, x_dtype = ctx.cfg
+        assert not inverse, "the inverse direction is inference-only"
+        b, t, C = xd.shape
+        dyc = None if dy is None else dy.float().contiguous()
+        dlc = None if dlogdet is None else dlogdet.float().contiguous()
+        dx = torch.empty_like(xd)
+        dm = torch.empty(C, dtype=torch.float32, device=xd.device)
+        dlogs = torch.empty(C, dtype=torch.float32, device=xd.device)
+        rc = _lib.lib().vits_flow_affine_bwd(xd.data_ptr(), ld.data_ptr(), lengths.data_ptr(), None if dyc is None else dyc.data_ptr(),
+                                             None if dlc is None else dlc.data_ptr(), dx.data_ptr(), dm.data_ptr(), dlogs.data_ptr(), b, t, C, swap,
+                                             _lib.stream_ptr())
+        _lib.check(rc, "vits_flow_affine_bwd")
+        return dx.to(x_dtype), dm.view(pshape), dlogs.view(pshape), None, None, None
+
+
+def flow_affine(x, m, logs, lengths, swap=False, inverse=False):
+    return FlowAffineFn.apply(x, m, logs, lengths, swap, inverse)
+
+
+class DequantLogFn(torch.autograd.Function):
+    """The variational-dequantisation + modules.Log step of StochasticDurationPredictor.forward (reference models.py:71-80):
+    z_q [b, t, 2] = [z_u, z1], w [b, t, 1] -> (z [b, t, 2] = [log(clamp((w - sigmoid(z_u) m) m)) m, z1],
+    s1 [b] = sum (logsigmoid(z_u) + logsigmoid(-z_u)) m, s2 [b] = sum -z[..., 0])."""
+
+    @staticmethod
+    def forward(ctx, zq, w, lengths):
+        _lib.require_cuda(zq, w, lengths)
+        zd, wd = zq.detach().float().contiguous(), w.detach().float().contiguous()
+        b, t, _ = zd.shape
+        out = torch.empty_like(zd)
+        s1 = torch.empty(b, dtype=torch.float32, device=zd.device)
+        s2 = torch.empty(b, dtype=torch.float32, device=zd.device)
+        rc = _lib.lib().vits_flow_dequant_log(zd.data_ptr(), wd.data_ptr(), lengths.data_ptr(), out.data_ptr(), s1.data_ptr(), s2.data_ptr(), b, t,
+                                              _lib.stream_ptr())
+        _lib.check(rc, "vits_flow_dequant_log")
+        ctx.save_for_backward(zd, wd, lengths)
+        ctx.zdtype = zq.dtype
+        return out, s1, s2
+
+    @staticmethod
+    def backward(ctx, dout, ds1, ds2):
+        zd, wd, lengths = ctx.saved_tensors
+        b, t, _ = zd.shape
+        c = lambda g: None if g is None else g.float().contiguous()
+        dout, ds1, ds2 = c(dout), c(ds1), c(ds2)
+        dz = torch.empty_like(zd)
+        p = lambda g: None if g is None else g.data_ptr()
+        rc = _lib.lib().vits_flow_dequant_log_bwd(zd.data_ptr(), wd.data_ptr(), lengths.data_ptr(), p(dout), p(ds1), p(ds2), dz.data_ptr(), b, t,
+                                                  _lib.stream_ptr())
+        _lib.check(rc, "vits_flow_dequant_log_bwd")
+        return dz.to(ctx.zdtype), None, None
+
+
+def dequant_log(zq, w, lengths):
+    return DequantLogFn.apply(zq, w, lengths)
