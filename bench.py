@@ -325,6 +325,7 @@ def main():
                         frac=d["algorithmic_GBps"] / HBM_PEAK_GBS, traffic=traffic, avg_launch_us=d["avg_launch_us"],
                         bytes_per_launch=sm["units_per_call"][1], launches_per_step=d["launches_per_step"],
                         mfma_TFLOPs=d["TFLOPs"], mfma_peak_TFLOPs=(2500.0 if not args.fp32 else 157.3),
+                        mfma_frac=(d["TFLOPs"] / (2500.0 if not args.fp32 else 157.3)) if d["TFLOPs"] else None,
                         note="algorithmic bytes = x + y (+res) + w once per launch, summed over the launches of one step, / their summed HIP-event time; "
                              "traffic (PMC FETCH_SIZE/WRITE_SIZE) is collected in separate rocprofv3 --pmc passes, see profiles/",
                         all_kernels=per_kernel)
