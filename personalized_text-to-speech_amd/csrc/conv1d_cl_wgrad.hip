@@ -85,11 +85,12 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
   const int wi = SMALL ? 0 : (wave >> 1), wj = SMALL ? 0 : (wave & 1);
   const int r = lane & 31, h = lane >> 5;
   const int n_ci_tiles = a.groups > 1 ? 1 : (a.Cin + CT - 1) / CT;
-  const int co0 = blockIdx.y * CT;
+  const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;      // (an XCD-aware remap of the ids was measured: no gain)
+  const int co0 = by * CT;
   const int og = a.groups > 1 ? a.Cout / a.groups : 1, ig = a.groups > 1 ? a.Cin / a.groups : 1;
   // grouped: the one ci tile that holds this co tile's diagonal blocks (host guarantees it is a single tile)
-  const int ci0 = a.groups > 1 ? ((co0 / og) * ig / CT) * CT : (blockIdx.z % n_ci_tiles) * CT;
-  const int tap0 = (blockIdx.z / n_ci_tiles) * KT;
+  const int ci0 = a.groups > 1 ? ((co0 / og) * ig / CT) * CT : (bz % n_ci_tiles) * CT;
+  const int tap0 = (bz / n_ci_tiles) * KT;
   const int ntap = (a.K - tap0 < KT) ? (a.K - tap0) : KT;
   // FLAT: chunks are TK consecutive rows of the joint (item, time) index and every tap has its own gathered
   // [TK][CT] tile (period-discriminator shapes: many short items, strided) — see csrc/conv1d_flat.hip.
@@ -99,6 +100,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
   unsigned char* ldsX = smem + (size_t)TK * PITCH;          // [xrows][CT] of act(X), first row = tap0's
   const int dvec = TK * VPR, xvec = xrows * VPR;
   const bool x_in_regs = xvec <= kThreads * XV;
+  const bool lrelu = a.in_slope != 1.0f;
 
   f32x16 acc[KT];
 #pragma unroll
@@ -132,7 +134,6 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
     }
     if (t >= 0 && t < t_in_hi && ci < a.Cin) {
       v = *reinterpret_cast<const u32x4*>(X + (size_t)t * a.ldx + ci);
-      if (a.in_slope != 1.0f) v = lrelu_vec<T>(v, a.in_slope);
     }
     return v;
   };
@@ -174,23 +175,27 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
       for (int i = 0; i < XV; ++i) {
         const int idx = tid + i * kThreads;
-        if (idx < xvec) *reinterpret_cast<u32x4*>(ldsX + (idx / VPR) * PITCH + (idx % VPR) * 16) = xr[i];
+        // the fused leaky-relu is applied here, AFTER the chunk's MFMAs, so that the loads stay in flight during them
+        if (idx < xvec) *reinterpret_cast<u32x4*>(ldsX + (idx / VPR) * PITCH + (idx % VPR) * 16) = lrelu ? lrelu_vec<T>(xr[i], a.in_slope) : xr[i];
       }
     } else {
       int b, t0, t_out_hi, t_in_hi;
       chunk_info(ch, b, t0, t_out_hi, t_in_hi);
       const T* X = static_cast<const T*>(a.x) + (size_t)b * a.T * a.ldx;
       for (int idx = tid; idx < xvec; idx += kThreads)
-        *reinterpret_cast<u32x4*>(ldsX + (idx / VPR) * PITCH + (idx % VPR) * 16) = load_x_vec(X, idx, t0, t_in_hi);
+      {
+        const u32x4 v = load_x_vec(X, idx, t0, t_in_hi);
+        *reinterpret_cast<u32x4*>(ldsX + (idx / VPR) * PITCH + (idx % VPR) * 16) = lrelu ? lrelu_vec<T>(v, a.in_slope) : v;
+      }
     }
   };
 
   // bias gradient = column sums of dY: done by the workgroups of ci-tile 0 / tap-group 0 on their staged tiles
-  const bool do_db = (a.partial_db != nullptr) && (blockIdx.z == 0);
+  const bool do_db = (a.partial_db != nullptr) && (bz == 0);
   float db_acc = 0.f;
 
   const int n_chunks = FLAT ? (a.B * a.Tout + TK - 1) / TK : a.B * a.chunks_per_item;
-  int ch = blockIdx.x;
+  int ch = bx;
   if (ch < n_chunks) { load_chunk(ch); store_chunk(ch); }
   __syncthreads();
   for (; ch < n_chunks; ch += a.S) {
@@ -222,19 +227,19 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
               (__attribute__((address_space(3))) unsigned char*)ldsD + (16 * s + rowk + 4 * rd) * PITCH + colA);
           fa.half[rd] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(pa);
         }
+        // every tap of the group unconditionally (no branch between the LDS reads and the MFMAs: the reads of a whole step are
+        // issued together).  A short last group (ntap < KT) multiplies stale LDS rows into accumulators that are never written.
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
-          if (k < ntap) {
-            union { s16x4 half[2]; bf16x8 v; } fb;
+          union { s16x4 half[2]; bf16x8 v; } fb;
 #pragma unroll
-            for (int rd = 0; rd < 2; ++rd) {
-              auto pb = reinterpret_cast<__attribute__((address_space(3))) s16x4*>(
-                  (__attribute__((address_space(3))) unsigned char*)ldsX +
-                  (FLAT ? (k * TK + 16 * s + rowk + 4 * rd) : ((16 * s + rowk + 4 * rd) * a.stride + k * a.dil)) * PITCH + colB);
-              fb.half[rd] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(pb);
-            }
-            acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, fb.v, acc[k], 0, 0, 0);
+          for (int rd = 0; rd < 2; ++rd) {
+            auto pb = reinterpret_cast<__attribute__((address_space(3))) s16x4*>(
+                (__attribute__((address_space(3))) unsigned char*)ldsX +
+                (FLAT ? (k * TK + 16 * s + rowk + 4 * rd) : ((16 * s + rowk + 4 * rd) * a.stride + k * a.dil)) * PITCH + colB);
+            fb.half[rd] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(pb);
           }
+          acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, fb.v, acc[k], 0, 0, 0);
         }
       }
     } else {
@@ -247,10 +252,8 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
         const float av = dA[(2 * s + h) * PF];
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
-          if (k < ntap) {
-            const float bv = xB[(FLAT ? (k * TK + 2 * s + h) : ((2 * s + h) * a.stride + k * a.dil)) * PF];
-            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[k], 0, 0, 0);
-          }
+          const float bv = xB[(FLAT ? (k * TK + 2 * s + h) : ((2 * s + h) * a.stride + k * a.dil)) * PF];
+          acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[k], 0, 0, 0);
         }
       }
     }
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
     red[tid] = db_acc;
     __syncthreads();
     if (tid < 64 && co0 + tid < a.Cout)
-      a.partial_db[(size_t)blockIdx.x * a.slab + co0 + tid] = red[tid] + red[tid + 64] + red[tid + 128] + red[tid + 192];
+      a.partial_db[(size_t)bx * a.slab + co0 + tid] = red[tid] + red[tid + 64] + red[tid + 128] + red[tid + 192];
     __syncthreads();
   }
   if constexpr (SMALL) {                                  // sum the four waves' accumulators (fixed order) into wave 0
@@ -290,7 +293,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
     }
   }
   // slab of this split: partial[split][tap][co][ci]
-  float* P = a.partial + (size_t)blockIdx.x * a.slab;
+  float* P = a.partial + (size_t)bx * a.slab;
   const int ci = ci0 + wj * 32 + r;
   const bool writer = ci < a.Cin && (!SMALL || wave == 0);
   // element index of accumulator (k, i) in dw's layout (dense, or compact for grouped layers); -1 = not an element of dw
@@ -323,7 +326,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
   __shared__ int is_last;
   __threadfence();
   __syncthreads();
-  const int tile = blockIdx.y * gridDim.z + blockIdx.z;
+  const int tile = by * gridDim.z + bz;
   if (tid == 0) is_last = (atomicAdd(&a.counters[tile], 1) == a.S - 1);
   __syncthreads();
   if (!is_last) return;
@@ -395,17 +398,21 @@ constexpr int kMaxSplits = 256;
 
 int taps_per_group(int k) { return k <= 4 ? k : (k <= 8 ? (k + 1) / 2 : 4); }
 
-// Number of (b,t)-reduction splits: enough workgroups to fill the chip (together with the tile and tap-group
-// dimensions), but never more slab traffic than ~2x the reads of x and dy (each split writes and re-reads one dW).
+// Number of (b,t)-reduction splits.  The grid should be ONE resident round of workgroups: a second, partly filled round
+// doubles the kernel's time (measured, tools/ubench_wgrad.py: 592 workgroups 57 us, 512 workgroups 39 us on the decoder's
+// 128-channel k = 7 layers).  Resident workgroups per CU: 2 by registers (acc + two prefetched tiles), 1 where the LDS tiles of
+// the flat-row variant with 3 taps (98 KB) or the registers of the SMALL variant with 4 taps bound it.  Never more slab traffic
+// than ~4x the reads of x and dy (each split writes and re-reads one dW).
 int pick_splits(int b, int t_out, int c_in, int c_out, int k, bool flat = false) {
   const int kt = flat ? (k < KT_FLAT ? k : KT_FLAT) : taps_per_group(k);
   const int groups = vits::ceil_div(c_out, CT) * vits::ceil_div(c_in, CT) * vits::ceil_div(k, kt);
   const int chunks = flat ? vits::ceil_div(b * t_out, TK) : b * vits::ceil_div(t_out, TK);
-  int s = vits::ceil_div(768, groups);
+  const bool small = !flat && c_out <= 32 && c_in <= 32;
+  const int slots = ((flat && kt == 3) || (small && kt == 4)) ? 256 : 512;
+  int s = groups <= slots ? slots / groups : vits::ceil_div(768, groups);
   const double io_elems = (double)b * t_out * (c_in + c_out);          // read once, 2 B (bf16) each
   const double dw_elems = (double)k * c_out * c_in;                    // each split writes + re-reads it in fp32: 8 B each
-  const int s_traffic = (int)(io_elems / dw_elems) + 1;                // slab bytes <= 4x activation bytes (measured: for these
-                                                                       // small layers parallelism beats the extra slab traffic)
+  const int s_traffic = (int)(io_elems / dw_elems) + 1;
   if (s > s_traffic) s = s_traffic;
   if (s > kMaxSplits) s = kMaxSplits;
   if (s > chunks) s = chunks;
@@ -447,7 +454,9 @@ int dispatch_k(const WgradArgs& a, hipStream_t s, bool flat) {
 }  // namespace
 
 extern "C" size_t vits_conv1d_cl_wgrad_workspace(int b, int t_out, int c_in, int c_out, int k) {
-  return (size_t)pick_splits(b, t_out, c_in, c_out, k) * ((size_t)k * c_out * c_in + c_out) * sizeof(float);
+  // the larger of the two variants' split counts: the caller does not know which kernel the launcher will take
+  const int s0 = pick_splits(b, t_out, c_in, c_out, k, false), s1 = pick_splits(b, t_out, c_in, c_out, k, true);
+  return (size_t)(s0 > s1 ? s0 : s1) * ((size_t)k * c_out * c_in + c_out) * sizeof(float);
 }
 
 static int wgrad_impl(const vits_wgrad_desc* desc, void* stream, vits_wgrad_pending* pending);
@@ -511,6 +520,7 @@ static int wgrad_impl(const vits_wgrad_desc* desc, void* stream, vits_wgrad_pend
   const vits::WgradRingPlan ring = vits::wgrad_ring_plan(d, t_out, S);
   if (ring.TC) S = ring.S;
   const size_t n = (size_t)d.k * d.c_out * (d.groups > 1 ? d.c_in / d.groups : d.c_in), nb = d.dbias ? (size_t)d.c_out : 0;   // multiples of 4
+  if ((size_t)S * (n + nb) * sizeof(float) > d.workspace_bytes) return VITS_E_BADARG;      // never write past the caller's slabs
   const bool accumulate = (d.flags & VITS_CONV_ACCUM) != 0;
   const bool direct = (S == 1) && !accumulate;           // a single split writes dw / db itself: no second launch
   float* ws = static_cast<float*>(d.workspace);

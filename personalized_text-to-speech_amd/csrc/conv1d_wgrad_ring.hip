@@ -52,10 +52,10 @@ __global__ __launch_bounds__(kThreads) void wgrad_ring_kernel(RArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wi = wave >> 1, wj = wave & 1;
   const int r = lane & 31, h = lane >> 5;
-  const int split = blockIdx.x;
-  const int co0 = blockIdx.y * TC;
-  const int ci0 = (blockIdx.z % a.n_ci_tiles) * TC;
-  const int tap0 = (blockIdx.z / a.n_ci_tiles) * KT;
+  const int split = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  const int co0 = by * TC;
+  const int ci0 = (bz % a.n_ci_tiles) * TC;
+  const int tap0 = (bz / a.n_ci_tiles) * KT;
   const int ntap = (a.K - tap0 < KT) ? (a.K - tap0) : KT;
   const int s = a.stride, Tout = a.Tout, M = a.M;
   const int halo = (ntap - 1) * a.dil + 1;
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_ring_kernel(RArgs a) {
   };
 
   // bias gradient = column sums of dY, by the workgroups of ci tile 0 / tap group 0: thread = one column x one slice of the rows
-  const bool do_db = a.partial_db != nullptr && blockIdx.z == 0;
+  const bool do_db = a.partial_db != nullptr && bz == 0;
   constexpr int DBP = kThreads / TC;                                  // row slices
   float db_acc = 0.f;
 

@@ -12,6 +12,7 @@ shapes = [  # b, t, ci, co, k, stride, dil, pad, in_slope
     (16, 201, 768, 192, 3, 1, 1, 1, 1.0), (16, 201, 192, 768, 3, 1, 1, 1, 1.0), (16, 500, 192, 384, 5, 1, 1, 2, 1.0), (16, 8192, 32, 32, 11, 1, 1, 5, 0.1),
 ]
 only = os.environ.get('UBW_ONLY')
+FLAGS = int(os.environ.get('UBW_FLAGS', '0'))
 for idx, (b, t, ci, co, kk, st, dl, pd, sl) in enumerate(shapes):
     if only and str(idx) not in only.split(','):
         continue
@@ -21,11 +22,11 @@ for idx, (b, t, ci, co, kk, st, dl, pd, sl) in enumerate(shapes):
     db = torch.empty(co, device="cuda")
     out = torch.empty(kk, co, ci, device="cuda")
     for _ in range(3):
-        K.conv1d_cl_wgrad_raw(x, dy, kk, pad=pd, stride=st, dil=dl, in_slope=sl, dbias=db, out=out)
+        K.conv1d_cl_wgrad_raw(x, dy, kk, pad=pd, stride=st, dil=dl, in_slope=sl, dbias=db, out=out, flags=FLAGS)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(20):
-        K.conv1d_cl_wgrad_raw(x, dy, kk, pad=pd, stride=st, dil=dl, in_slope=sl, dbias=db, out=out)
+        K.conv1d_cl_wgrad_raw(x, dy, kk, pad=pd, stride=st, dil=dl, in_slope=sl, dbias=db, out=out, flags=FLAGS)
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 20 * 1e3
     fl = 2.0 * b * t_out * ci * co * kk
