@@ -16,7 +16,13 @@ ALL_SHAPES = [  # b, t, c_in, c_out, k, stride, dil, pad, tag
     (16, 256, 256, 256, 11, 1, 1, 5, "dec256.k11"), (16, 256, 256, 256, 3, 1, 1, 1, "dec256.k3"),
     (16, 2048, 128, 128, 11, 1, 1, 5, "dec128.k11"), (16, 2048, 128, 128, 3, 1, 5, 5, "dec128.k3d5"), (16, 2048, 128, 128, 7, 1, 1, 3, "dec128.k7"),
     (16, 4096, 64, 64, 11, 1, 1, 5, "dec64.k11"), (16, 201, 192, 192, 1, 1, 1, 0, "t201.1x1"), (16, 500, 192, 192, 1, 1, 1, 0, "t500.1x1"),
-    (16, 201, 208, 96, 1, 1, 1, 0, "t201.pv"), (16, 201, 768, 192, 3, 1, 1, 1, "ffn2"), (16, 201, 192, 768, 3, 1, 1, 1, "ffn1"),
+    (16, 2048, 256, 128, 1, 1, 1, 0, "up3.dgrad"), (16, 32, 4096, 512, 1, 1, 1, 0, "up1.dgrad"), (16, 256, 2048, 256, 1, 1, 1, 0, "up2.dgrad"),
+    (16, 4096, 128, 64, 1, 1, 1, 0, "up4.dgrad"), (16, 32, 512, 4096, 1, 1, 1, 0, "up1.fwd"), (16, 256, 256, 2048, 1, 1, 1, 0, "up2.fwd"),
+    (16, 2048, 128, 256, 1, 1, 1, 0, "up3.fwd"), (16, 4096, 64, 128, 1, 1, 1, 0, "up4.fwd"), (16, 1, 6144, 256, 1, 1, 1, 0, "cond.dgrad16"),
+    (16, 1, 1536, 256, 1, 1, 1, 0, "cond.dgrad4"), (16, 1, 256, 6144, 1, 1, 1, 0, "cond.fwd16"),
+    (16, 201, 208, 96, 1, 1, 1, 0, "t201.pv"),
+    (32, 8192, 16, 64, 41, 4, 1, 20, "S.L2:g4"), (32, 2048, 64, 256, 41, 4, 1, 20, "S.L3:g16"), (32, 512, 256, 1024, 41, 4, 1, 20, "S.L4:g64"),
+    (32, 128, 1024, 1024, 41, 4, 1, 20, "S.L5:g256"), (352, 248, 32, 128, 5, 3, 1, 2, "P11.L2"), (16, 201, 768, 192, 3, 1, 1, 1, "ffn2"), (16, 201, 192, 768, 3, 1, 1, 1, "ffn1"),
 ]
 SHAPES = [x for x in ALL_SHAPES if not os.environ.get("UB_ONLY") or x[-1] in os.environ["UB_ONLY"].split(",")]
 N = 32
@@ -27,7 +33,8 @@ for (b, t, ci, co, k, st, dl, pd, tag) in SHAPES:
     bias = torch.randn(co, device=DEV)
     t_out = (t + 2 * pd - dl * (k - 1) - 1) // st + 1
     y = torch.empty(b, t_out, co, device=DEV, dtype=torch.bfloat16)
-    run = lambda: K.conv1d_cl_raw(x, w, bias, out=y, pad=pd, stride=st, dil=dl, out_slope=0.1)
+    groups = int(tag.split(":g")[1]) if ":g" in tag else 1
+    run = lambda: K.conv1d_cl_raw(x, w, bias, out=y, pad=pd, stride=st, dil=dl, out_slope=0.1, groups=groups)
     for _ in range(3):
         run()
     torch.cuda.synchronize()
