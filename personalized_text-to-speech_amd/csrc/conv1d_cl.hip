@@ -131,6 +131,7 @@ __global__ __launch_bounds__(kThreads) void conv1d_cl_kernel(ConvArgs args) {
   const int n_stages = n_groups * n_chunks;
   const int xvec = xrows * VPR;
   const bool x_in_regs = xvec <= kThreads * XV;        // else: stage X synchronously (long strided tiles)
+  const bool lrelu_in = a.in_slope != 1.0f;
 
   u32x4 xr[XV], wr[WV];
   auto load_x = [&](int ci0) {
@@ -141,10 +142,7 @@ __global__ __launch_bounds__(kThreads) void conv1d_cl_kernel(ConvArgs args) {
       if (idx < xvec) {
         const int row = idx / VPR, ch = idx % VPR;
         const int t = t0 * a.stride - a.pad + row, ci = ci0 + ch * V;
-        if (t >= 0 && t < t_in_hi && ci < a.c_in) {
-          v = *reinterpret_cast<const u32x4*>(X + (size_t)t * a.ldx + ci);
-          if (a.in_slope != 1.0f) v = lrelu_vec<T>(v, a.in_slope);
-        }
+        if (t >= 0 && t < t_in_hi && ci < a.c_in) v = *reinterpret_cast<const u32x4*>(X + (size_t)t * a.ldx + ci);
       }
       xr[i] = v;
     }
@@ -153,7 +151,8 @@ __global__ __launch_bounds__(kThreads) void conv1d_cl_kernel(ConvArgs args) {
 #pragma unroll
     for (int i = 0; i < XV; ++i) {
       const int idx = tid + i * kThreads;
-      if (idx < xvec) *reinterpret_cast<u32x4*>(ldsX + (idx / VPR) * PITCHK + (idx % VPR) * 16) = xr[i];
+      // the fused input leaky-relu runs here, after the stage's MFMAs: the loads stay in flight during them
+      if (idx < xvec) *reinterpret_cast<u32x4*>(ldsX + (idx / VPR) * PITCHK + (idx % VPR) * 16) = lrelu_in ? lrelu_vec<T>(xr[i], a.in_slope) : xr[i];
     }
   };
   auto stage_x_direct = [&](int ci0) {
@@ -233,10 +232,7 @@ __global__ __launch_bounds__(kThreads) void conv1d_cl_kernel(ConvArgs args) {
             const int row = idx >> 3, ch = idx & 7;
             const int t = t0 - a.pad + row, ci = c * KC + ch * V;
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (t >= 0 && t < t_in_hi && ci < a.c_in) {
-              v = *reinterpret_cast<const u32x4*>(X + (size_t)t * a.ldx + ci);
-              if (a.in_slope != 1.0f) v = lrelu_vec<T>(v, a.in_slope);
-            }
+            if (t >= 0 && t < t_in_hi && ci < a.c_in) v = *reinterpret_cast<const u32x4*>(X + (size_t)t * a.ldx + ci);
             xr[c * XS + j] = v;
           }
 #pragma unroll
@@ -257,7 +253,7 @@ __global__ __launch_bounds__(kThreads) void conv1d_cl_kernel(ConvArgs args) {
 #pragma unroll
           for (int j = 0; j < XS; ++j) {
             const int idx = tid + j * kThreads;
-            *reinterpret_cast<u32x4*>(ldsX + (idx >> 3) * PITCHK + (idx & 7) * 16) = xr[c * XS + j];
+            *reinterpret_cast<u32x4*>(ldsX + (idx >> 3) * PITCHK + (idx & 7) * 16) = lrelu_in ? lrelu_vec<T>(xr[c * XS + j], a.in_slope) : xr[c * XS + j];
           }
 #pragma unroll
           for (int j = 0; j < WS; ++j) {

@@ -156,10 +156,7 @@ __global__ __launch_bounds__(kThreads) void conv1d_flat_kernel(FlatArgs args) {
         if (num >= 0 && on_grid && ci < a.c_in) {
           int hi = a.t;
           if (a.flags & VITS_CONV_MASK_IN) { const int len = a.lengths[xs_b[i]]; hi = len < a.t ? len : a.t; }
-          if (ti < hi) {
-            v = *reinterpret_cast<const u32x4*>(X + ((size_t)xs_b[i] * a.t + ti) * a.ldx + ci);
-            if (a.in_slope != 1.0f) v = lrelu_vec<T>(v, a.in_slope);
-          }
+          if (ti < hi) v = *reinterpret_cast<const u32x4*>(X + ((size_t)xs_b[i] * a.t + ti) * a.ldx + ci);
         }
       }
       xr[i] = v;
@@ -182,7 +179,8 @@ __global__ __launch_bounds__(kThreads) void conv1d_flat_kernel(FlatArgs args) {
 #pragma unroll
     for (int i = 0; i < XVF; ++i) {
       const int idx = tid + i * kThreads;
-      if (idx < ntap * TMW * 8) *reinterpret_cast<u32x4*>(ldsX + (idx >> 3) * PITCH + (idx & 7) * 16) = xr[i];
+      // (the fused input leaky-relu runs here, after the stage's MFMAs: the loads stay in flight during them)
+      if (idx < ntap * TMW * 8) *reinterpret_cast<u32x4*>(ldsX + (idx >> 3) * PITCH + (idx & 7) * 16) = (a.in_slope != 1.0f) ? lrelu_vec<T>(xr[i], a.in_slope) : xr[i];
     }
 #pragma unroll
     for (int i = 0; i < WVF; ++i) {
