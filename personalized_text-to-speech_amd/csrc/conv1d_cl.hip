@@ -423,6 +423,59 @@ int dispatch_tile(const vits_conv_desc& d, int t_out, hipStream_t s) {
   return launch_conv<T, 1, 4>(d, t_out, s);                           // 128 x 32
 }
 
+
+// ---- products with very few rows and a long reduction (the conditioning layers' data gradient: [16] x [6144] -> [256], K = 6144):
+// the tiled kernels would put 4 workgroups on the chip and walk ~100 channel chunks each.  Here one WORKGROUP owns one output
+// channel: its 256 lanes stride over the reduction (16-byte loads of W and of every row of X), fp32 sums per row, a fixed-order
+// butterfly across the lanes of a wave, the four waves' sums added in wave order through LDS; lane m writes row m.
+// Deterministic; bias and scale as in the common epilogue.
+constexpr int SMALLM_ROWS = 16;
+__global__ __launch_bounds__(256) void small_m_kernel(const __bf16* __restrict__ X, const __bf16* __restrict__ W, const float* __restrict__ bias,
+                                                      __bf16* __restrict__ Y, int M, int N, int Kc, int ldx, int ldw, int ldy, float scale) {
+  __shared__ float red[4][SMALLM_ROWS];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = blockIdx.x;
+  float acc[SMALLM_ROWS];
+#pragma unroll
+  for (int m = 0; m < SMALLM_ROWS; ++m) acc[m] = 0.f;
+  const __bf16* wrow = W + (size_t)n * ldw;
+  for (int kk = threadIdx.x * 8; kk < Kc; kk += 256 * 8) {
+    union { u32x4 u; __bf16 e[8]; } wv;
+    wv.u = *reinterpret_cast<const u32x4*>(wrow + kk);
+    float wf[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wf[j] = (float)wv.e[j];
+#pragma unroll
+    for (int m = 0; m < SMALLM_ROWS; ++m) {
+      if (m < M) {
+        union { u32x4 u; __bf16 e[8]; } xv;
+        xv.u = *reinterpret_cast<const u32x4*>(X + (size_t)m * ldx + kk);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[m] = fmaf(wf[j], (float)xv.e[j], acc[m]);
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < SMALLM_ROWS; ++m) {
+    float v = acc[m];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) red[wave][m] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < M) {
+    const int m = threadIdx.x;
+    const float v = ((red[0][m] + red[1][m]) + red[2][m]) + red[3][m];
+    Y[(size_t)m * ldy + n] = (__bf16)((v + (bias ? bias[n] : 0.f)) * scale);
+  }
+}
+
+bool small_m_applies(const vits_conv_desc& d, int t_out) {
+  return d.dtype == VITS_DT_BF16 && d.k == 1 && d.stride == 1 && d.in_div <= 1 && d.groups <= 1 && d.pad == 0 && d.w_batch_stride == 0 &&
+         (long)d.b * t_out <= SMALLM_ROWS && t_out == d.t && d.c_in >= 1024 && d.c_in % 8 == 0 && d.ldx % 8 == 0 && d.ldw % 8 == 0 &&
+         d.flags == 0 && d.in_slope == 1.0f && !d.res && !d.mg_src && !d.bias_b && !d.y2;
+}
+
 }  // namespace
 
 extern "C" int vits_conv1d_cl(const vits_conv_desc* desc, void* stream) {
@@ -454,6 +507,11 @@ extern "C" int vits_conv1d_cl(const vits_conv_desc* desc, void* stream) {
   const int vec = d.dtype == VITS_DT_BF16 ? 8 : (d.dtype == VITS_DT_F32 ? 4 : 0);
   if (vec == 0) return VITS_E_UNSUPPORTED;
   if (d.c_in % vec != 0 || d.ldx % vec != 0 || d.ldw % vec != 0 || d.w_batch_stride % vec != 0) return VITS_E_UNSUPPORTED;
+  if (small_m_applies(d, t_out)) {
+    hipLaunchKernelGGL(small_m_kernel, dim3(d.c_out), dim3(256), 0, s, static_cast<const __bf16*>(d.x), static_cast<const __bf16*>(d.w),
+                       d.bias, static_cast<__bf16*>(d.y), d.b * t_out, d.c_out, d.c_in, d.ldx, d.ldw, d.ldy, d.out_scale);
+    return vits::check_launch("vits_conv1d_cl/small_m");
+  }
   // flat-row kernel: strided / divided launches, and short sequences spread over many items (most of a per-item
   // time tile would be empty).  It has no gate epilogues and no per-item operands.
   const bool flat_ok = !gate && !gate_bwd && d.w_batch_stride == 0 && d.y2 == nullptr;

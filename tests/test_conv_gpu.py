@@ -42,6 +42,24 @@ def test_plain_conv(pkg, case, dtype, tol):
     assert rel(y, ref_conv(x, w, bias, dil, pad, 1.0)) < tol
 
 
+@pytest.mark.parametrize("case", [(16, 1, 6144, 256), (16, 1, 1536, 256), (5, 1, 1032, 77), (2, 7, 2048, 130)])
+def test_few_rows_long_reduction_kernel(pkg, case):
+    """b * t <= 16 rows, k = 1, c_in >= 1024 (the conditioning layers' data gradient): the wave-per-output-channel kernel;
+    bias, scale, strided rows, reproducible."""
+    b, t, ci, co = case
+    torch.manual_seed(ci)
+    xw = torch.randn(b, t, ci + 8, device=DEV).bfloat16()
+    x = xw[:, :, :ci]                                            # row pitch ci + 8
+    w = (torch.randn(1, co, ci, device=DEV) / ci ** 0.5).bfloat16()
+    bias = torch.randn(co, device=DEV)
+    y = pkg.kernels.conv1d_cl_raw(x, w, bias, out_scale=0.5)
+    want = ref_conv(x, w, bias, 1, 0, 1.0) * 0.5
+    assert rel(y, want) < 1e-2
+    assert torch.equal(y, pkg.kernels.conv1d_cl_raw(x, w, bias, out_scale=0.5))
+    y0 = pkg.kernels.conv1d_cl_raw(x, w)
+    assert rel(y0, ref_conv(x, w, None, 1, 0, 1.0)) < 1e-2
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1.5e-2)])
 def test_fused_prologue_epilogue(pkg, dtype, tol):
     torch.manual_seed(3)
