@@ -332,6 +332,22 @@ int vits_lrelu_mask_bwd(int dtype, const void* dy, const void* y, float slope, c
                         void* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Grouped strided convolutions of DiscriminatorS (reference models.py:343-349: 4 input channels per group, 16 or 4 output
+ * channels per group, k = 41, stride 4) as direct kernels — csrc/grouped.hip.  bf16 only (VITS_E_UNSUPPORTED otherwise, and
+ * for other group shapes: the caller then uses vits_conv1d_cl with `groups`).
+ *   x [n][t_in][c_in], y [n][t_out][c_out] channels-last, t_out = (t_in + 2 pad - k) / stride + 1;
+ *   w = the DENSE block-diagonal operand [k][c_out][c_in] vits_conv1d_cl takes for the same layer (only the diagonal blocks are
+ *   read) — for both directions;
+ *   fwd:   y = leaky_relu(conv(x) + bias, out_slope);
+ *   dgrad: dx = (conv^T(dy) + res) * (mg_src > 0 ? 1 : mg_slope)   (res, mg_src optional, [n][t_in][c_in]).
+ *   (The weight gradient of these layers stays on vits_conv1d_cl_wgrad with `groups`: a direct form was measured no faster.)
+ * ------------------------------------------------------------------------------------------ */
+int vits_grouped_conv_fwd(int dtype, const void* x, const void* w, const float* bias, void* y, int n, int t_in, int c_in, int c_out,
+                          int k, int stride, int pad, int groups, float out_slope, void* stream);
+int vits_grouped_conv_dgrad(int dtype, const void* dy, const void* w, const void* res, const void* mg_src, void* dx, int n, int t_in,
+                            int c_in, int c_out, int k, int stride, int pad, int groups, float mg_slope, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Discriminator edge layers as bandwidth kernels (csrc/disc_edge.hip).
  *
  * Replaces: the first convolution of every discriminator together with the pad / view it sits behind —

@@ -10,7 +10,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvitsmi.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 c_int = ctypes.c_int
 c_void_p = ctypes.c_void_p
@@ -49,6 +49,8 @@ SIGNATURES = {
     "vits_conv1d_cl_wgrad_deferred": (c_int, [c_void_p, c_void_p, c_void_p]),
     "vits_wgrad_reduce_pending": (c_int, [c_void_p, c_int, c_void_p]),
     "vits_conv1d_cl": (c_int, [c_void_p, c_void_p]),
+    "vits_grouped_conv_fwd": (c_int, [c_int] + [c_void_p] * 4 + [c_int] * 8 + [c_float, c_void_p]),
+    "vits_grouped_conv_dgrad": (c_int, [c_int] + [c_void_p] * 5 + [c_int] * 8 + [c_float, c_void_p]),
     "vits_disc_first_rows": (c_int, [c_int] * 5),
     "vits_disc_first_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_float, c_void_p]),
     "vits_disc_first_wgrad_workspace": (c_size_t, [c_int] * 7),

@@ -44,6 +44,41 @@ def first_fwd(x, w, bias, p, k, s1, pad, c_out, dtype):
     return y
 
 
+def grouped_direct_ok(x, c_in, c_out, k, stride, groups):
+    """The group shapes csrc/grouped.hip covers (DiscriminatorS, models.py:343-349), bf16 on the GPU only."""
+    return (x.is_cuda and x.dtype == torch.bfloat16 and groups > 1 and groups % 4 == 0 and c_in == 4 * groups and
+            c_out // groups in (4, 16) and c_out % groups == 0 and k <= 64 and stride <= 4)
+
+
+def grouped_fwd(x, w, bias, k, stride, pad, groups):
+    """leaky_relu(grouped conv(x) + bias): x [n][t][c_in], w the dense block-diagonal operand [k][c_out][c_in]."""
+    _lib.require_cuda(x, w)
+    n, t, c_in = x.shape
+    c_out = w.size(1)
+    assert x.is_contiguous() and w.is_contiguous() and tuple(w.shape) == (k, c_out, c_in) and w.dtype == x.dtype
+    y = torch.empty((n, (t + 2 * pad - k) // stride + 1, c_out), device=x.device, dtype=x.dtype)
+    rc = _lib.lib().vits_grouped_conv_fwd(_DT[x.dtype], x.data_ptr(), w.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(),
+                                          n, t, c_in, c_out, k, stride, pad, groups, SLOPE, _lib.stream_ptr())
+    _lib.check(rc, "vits_grouped_conv_fwd")
+    return y
+
+
+def grouped_dgrad(dy, w, res, mg_src, t_in, k, stride, pad, groups):
+    """(conv^T(dy) + res) * lrelu'(mg_src): dy [n][t_out][c_out], res / mg_src [n][t_in][c_in]."""
+    _lib.require_cuda(dy, w)
+    n, t_out, c_out = dy.shape
+    c_in = w.size(2)
+    assert dy.is_contiguous() and w.is_contiguous() and tuple(w.shape) == (k, c_out, c_in) and (t_in + 2 * pad - k) // stride + 1 == t_out
+    for t in (res, mg_src):
+        assert t is None or (t.is_contiguous() and tuple(t.shape) == (n, t_in, c_in) and t.dtype == dy.dtype)
+    dx = torch.empty((n, t_in, c_in), device=dy.device, dtype=dy.dtype)
+    rc = _lib.lib().vits_grouped_conv_dgrad(_DT[dy.dtype], dy.data_ptr(), w.data_ptr(), None if res is None else res.data_ptr(),
+                                            None if mg_src is None else mg_src.data_ptr(), dx.data_ptr(), n, t_in, c_in, c_out, k, stride,
+                                            pad, groups, SLOPE, _lib.stream_ptr())
+    _lib.check(rc, "vits_grouped_conv_dgrad")
+    return dx
+
+
 def first_wgrad(x, dy, dw, p, k, s1, pad, c_out):
     """dw: float32 [k][c_out][8] (column 0 written); returns dbias float32 [c_out]."""
     n, T = x.shape
@@ -167,7 +202,10 @@ class DiscFn(torch.autograd.Function):
             it += 2
             hs = [h]
             for (ci, co, kk, st, pd, _), g in zip(plan.mid, grp):
-                h = C(h, R[it].fwd, _f32(wb[it + 1]), pad=pd, stride=st, out_slope=SLOPE, groups=g)
+                if grouped_direct_ok(h, ci, co, kk, st, g):
+                    h = grouped_fwd(h, R[it].fwd, _f32(wb[it + 1]), kk, st, pd, g)
+                else:
+                    h = C(h, R[it].fwd, _f32(wb[it + 1]), pad=pd, stride=st, out_slope=SLOPE, groups=g)
                 it += 2
                 hs.append(h)
             pk, ppad, _ = plan.post
@@ -233,8 +271,11 @@ class DiscFn(torch.autograd.Function):
                     db = torch.empty(co, device=xd.device, dtype=torch.float32)
                     grads[iw] = WG(x_in, dcur, kk, pad=pd, stride=st, out=R[iw].claim_dw(ctx), dbias=db, groups=g, defer=defer)
                     grads[iw + 1] = db
-                dcur = C(dcur, WA.bwd_operand(R[iw]), None, res=None if dprev is None else cont(dprev[lo:]), mg_src=x_in, mg_slope=SLOPE,
-                         pad=(kk - 1) - pd, in_div=st, t_out=x_in.size(1) if st != 1 else None, groups=g)
+                if grouped_direct_ok(dcur, ci, co, kk, st, g):
+                    dcur = grouped_dgrad(cont(dcur), R[iw].fwd, None if dprev is None else cont(dprev[lo:]), cont(x_in), x_in.size(1), kk, st, pd, g)
+                else:
+                    dcur = C(dcur, WA.bwd_operand(R[iw]), None, res=None if dprev is None else cont(dprev[lo:]), mg_src=x_in, mg_slope=SLOPE,
+                             pad=(kk - 1) - pd, in_div=st, t_out=x_in.size(1) if st != 1 else None, groups=g)
             # ---- first layer
             if dcur is not None:
                 k, s1, pad, c1 = plan.first

@@ -386,3 +386,39 @@ def test_large_tile_wgrad_kernel_matches_emulation(pkg):
         K.conv1d_cl_wgrad_raw(x, dy, kk, pad=pd, stride=st, dil=dl, in_slope=sl, out=acc_a, flags=K.CONV_ACCUM | big)
         cl_emul.conv1d_cl_wgrad_raw(x, dy, kk, pad=pd, stride=st, dil=dl, in_slope=sl, out=acc_b, flags=K.CONV_ACCUM)
         assert rel(acc_a, acc_b) < tol, ("accum", b, t, ci, co, kk)
+
+
+@pytest.mark.parametrize("case", [(3, 203, 4, 16, 41, 4, 20), (2, 64, 8, 4, 41, 4, 20), (2, 1030, 16, 16, 41, 4, 20), (1, 45, 4, 4, 7, 3, 2), (2, 130, 8, 16, 5, 1, 2)])
+def test_grouped_direct_kernels_match_torch(pkg, case):
+    """csrc/grouped.hip (DiscriminatorS' grouped layers as direct kernels) against torch's grouped conv1d in fp32 on the
+    bf16-rounded operands: forward (bias + leaky-relu) and data gradient ((conv^T(dy) + res) * lrelu'(mg))."""
+    n, t, groups, og, k, stride, pad = case
+    from importlib import import_module
+    D = import_module(pkg.__name__ + ".disc_cl")
+    torch.manual_seed(t)
+    ci, co = 4 * groups, og * groups
+    x = torch.randn(n, t, ci, device=DEV).bfloat16()
+    wc = (torch.randn(co, 4, k, device=DEV) / (4 * k) ** 0.5).bfloat16()          # torch layout [c_out][c_in / groups][k]
+    bias = torch.randn(co, device=DEV)
+    dense = torch.zeros(k, co, ci, device=DEV, dtype=torch.bfloat16)
+    for g in range(groups):
+        dense[:, g * og:(g + 1) * og, g * 4:(g + 1) * 4] = wc[g * og:(g + 1) * og].permute(2, 0, 1)
+    assert D.grouped_direct_ok(x, ci, co, k, stride, groups)
+    y = D.grouped_fwd(x, dense, bias, k, stride, pad, groups)
+    xr = x.float().transpose(1, 2).requires_grad_(True)
+    pre = F.conv1d(xr, wc.float(), bias, stride, pad, 1, groups)
+    want = F.leaky_relu(pre, D.SLOPE).transpose(1, 2).detach()
+    assert tuple(y.shape) == tuple(want.shape) and rel(y, want) < 1e-2
+    assert torch.equal(y, D.grouped_fwd(x, dense, bias, k, stride, pad, groups))
+    # the same layer through the matrix-core path
+    y_mc = pkg.kernels.conv1d_cl_raw(x, dense, bias, pad=pad, stride=stride, out_slope=D.SLOPE, groups=groups)
+    assert rel(y, y_mc) < 1.5e-2
+    dy = torch.randn_like(y)
+    res = torch.randn(n, t, ci, device=DEV).bfloat16()
+    mg = torch.randn(n, t, ci, device=DEV).bfloat16()
+    (gx,) = torch.autograd.grad(pre, xr, dy.float().transpose(1, 2))
+    want_dx = (gx.transpose(1, 2) + res.float()) * torch.where(mg.float() > 0, 1.0, D.SLOPE)
+    dx = D.grouped_dgrad(dy, dense, res, mg, t, k, stride, pad, groups)
+    assert rel(dx, want_dx) < 1e-2
+    dx0 = D.grouped_dgrad(dy, dense, None, None, t, k, stride, pad, groups)
+    assert rel(dx0, gx.transpose(1, 2)) < 1e-2
