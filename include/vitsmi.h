@@ -340,12 +340,19 @@ int vits_lrelu_mask_bwd(int dtype, const void* dy, const void* y, float slope, c
  *   read) — for both directions;
  *   fwd:   y = leaky_relu(conv(x) + bias, out_slope);
  *   dgrad: dx = (conv^T(dy) + res) * (mg_src > 0 ? 1 : mg_slope)   (res, mg_src optional, [n][t_in][c_in]).
- *   (The weight gradient of these layers stays on vits_conv1d_cl_wgrad with `groups`: a direct form was measured no faster.)
+ *   wgrad (16 output channels per group only): the compact dw [k][c_out][c_in / groups] (+)= and dbias [c_out] (+)= as
+ *          vits_conv1d_cl_wgrad_deferred writes them for `groups` > 1: per-split fp32 slabs in `workspace`
+ *          (>= vits_grouped_conv_wgrad_workspace bytes), summed in split order by vits_wgrad_reduce_pending with the entry
+ *          returned in `pending` (required).
  * ------------------------------------------------------------------------------------------ */
 int vits_grouped_conv_fwd(int dtype, const void* x, const void* w, const float* bias, void* y, int n, int t_in, int c_in, int c_out,
                           int k, int stride, int pad, int groups, float out_slope, void* stream);
 int vits_grouped_conv_dgrad(int dtype, const void* dy, const void* w, const void* res, const void* mg_src, void* dx, int n, int t_in,
                             int c_in, int c_out, int k, int stride, int pad, int groups, float mg_slope, void* stream);
+size_t vits_grouped_conv_wgrad_workspace(int n, int t_out, int c_out, int k, int groups);
+int vits_grouped_conv_wgrad(int dtype, const void* x, const void* dy, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
+                            int n, int t_in, int c_in, int c_out, int k, int stride, int pad, int groups, int accumulate,
+                            vits_wgrad_pending* pending, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Discriminator edge layers as bandwidth kernels (csrc/disc_edge.hip).

@@ -14,8 +14,9 @@
 //     that the per-tap read is lane-consecutive.  This form is bound by the scalar cache (one 8-byte piece per line: its misses
 //     are serialised — 120 us on the 16-channel layers before the matrix-core form), fine for the small layer 5;
 //   * fp32 accumulation, bias + leaky-relu epilogue (forward), (acc + res) * lrelu'(mg_src) (data gradient) as in vits_conv1d_cl.
-// The weight gradient of these layers stays on vits_conv1d_cl_wgrad: a direct form (thread = (tap, channel), dY rows broadcast from
-// LDS) was built and measured no faster (152 vs 112 us).
+// The weight gradient (16 output channels per group) is a matrix-core product too, see grouped_wgrad_mfma_kernel: 24 us per layer;
+// a VALU form (thread = (tap, channel), dY rows broadcast from LDS) was built first and measured no faster than the tiled kernel
+// (152 vs 112 us).
 #include "common.h"
 
 namespace {
@@ -295,6 +296,111 @@ __global__ __launch_bounds__(256) void grouped_dgrad_mfma_kernel(GArgs a, int r_
   }
 }
 
+// ---- weight gradient on the matrix cores (16 output channels per group): dw[tap][g*16 + o][c] = sum_{n, t} dy[n][t][o] * x[n][t*stride + tap - pad][c]
+// is, per group, the product [16 o] x [t] x [(tap, c)]: rows = o, the reduction runs over the output times, the columns are the
+// 4 k (<= 176) pairs kk = tap*4 + c in 11 tiles of 16.  Both operands are needed TIME-major per lane (8 consecutive t), so the tile's
+// dY rows are staged transposed ([o][t]) and the input window de-interleaved and transposed ([row mod stride][c][row / stride]:
+// for a fixed tap the times t, t+1, .. are consecutive entries).  A = one 16-byte read, B = 8 two-byte reads per fragment; the bias
+// gradient is one more MFMA against a vector of ones.  Workgroup = 4 adjacent groups (they share the staged rows) x one split of the
+// (item, 64-time tile) list; every split writes its fp32 slab (compact [k][c_out][4] + [c_out]), summed in split order by
+// vits_wgrad_reduce_pending (bitwise reproducible).
+constexpr int NT_W = 11;                                   // column tiles: 11 x 16 = 176 >= 4 * 41 + (padding pairs, skipped)
+constexpr int WIDX = TT + KMAXG / 1 + 8;                   // entries per (phase, c) row of the transposed window (row / stride < 64 + k)
+struct GWArgs {
+  const __bf16* x; const __bf16* dy; float* partial; float* partial_db;
+  int n, T_in, T_out, C_in, C_out, k, stride, pad, S, tiles_per_item;
+  size_t slab;
+};
+
+__global__ __launch_bounds__(256) void grouped_wgrad_mfma_kernel(GWArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned short dyT[4][16][TT + 8];           // [group][o][t]
+  __shared__ unsigned short xT[4][SMAXG][IG][WIDX];                                    // [group][row % s][c][row / s]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int split = blockIdx.x, g4 = blockIdx.y * 4;
+  const int g = g4 + wave;
+  const int s = a.stride;
+  const int l16 = lane & 15, kq = lane >> 4;
+  f32x4_t acc[NT_W], accb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < NT_W; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  // column (tap, c) of this lane in every tile, as the offset into xT of time 0: tap % s plane, channel c, entry tap / s
+  int xoff[NT_W];
+#pragma unroll
+  for (int j = 0; j < NT_W; ++j) {
+    const int kk = j * 16 + l16, tap = kk >> 2, c = kk & 3;
+    xoff[j] = tap < a.k ? ((tap % s) * IG + c) * WIDX + tap / s : -1;
+  }
+  union { bf16x8_t v; unsigned short e[8]; } ones;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ones.e[i] = 0x3F80;          // bf16 1.0
+  const int n_tiles = a.n * a.tiles_per_item;
+  const int nrows = (TT - 1) * s + a.k;
+  for (int tile = split; tile < n_tiles; tile += a.S) {
+    const int n = tile / a.tiles_per_item, t0 = (tile - n * a.tiles_per_item) * TT;
+    const int rows = (a.T_out - t0 < TT) ? (a.T_out - t0) : TT;
+    __syncthreads();                                        // the previous tile's staged rows have been consumed
+    const __bf16* X = a.x + (size_t)n * a.T_in * a.C_in + (size_t)g4 * IG;
+    for (int idx = tid; idx < nrows * 2; idx += 256) {
+      const int r = idx >> 1, half = idx & 1;
+      const int tin = t0 * s - a.pad + r;
+      union { u32x4 u; unsigned short e[8]; } v;
+      v.u = u32x4{0u, 0u, 0u, 0u};
+      if (tin >= 0 && tin < a.T_in) v.u = *reinterpret_cast<const u32x4*>(X + (size_t)tin * a.C_in + half * 8);
+      const int ph = r % s, ix = r / s;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xT[half * 2 + (e >> 2)][ph][e & 3][ix] = v.e[e];
+    }
+    const __bf16* DY = a.dy + ((size_t)n * a.T_out + t0) * a.C_out + (size_t)g4 * 16;
+    for (int idx = tid; idx < TT * 8; idx += 256) {
+      const int r = idx >> 3, vc = idx & 7;
+      union { u32x4 u; unsigned short e[8]; } v;
+      v.u = u32x4{0u, 0u, 0u, 0u};
+      if (r < rows) v.u = *reinterpret_cast<const u32x4*>(DY + (size_t)r * a.C_out + vc * 8);      // rows past the item's end count as zero
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dyT[vc >> 1][(vc & 1) * 8 + e][r] = v.e[e];
+    }
+    __syncthreads();
+    const unsigned short* xg = &xT[wave][0][0][0];
+#pragma unroll
+    for (int ks = 0; ks < TT / 32; ++ks) {
+      const int tb = ks * 32 + kq * 8;                      // first of this lane's 8 times
+      union { bf16x8_t v; u32x4 u; } fa;
+      fa.u = *reinterpret_cast<const u32x4*>(&dyT[wave][l16][tb]);
+      accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.v, ones.v, accb, 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < NT_W; ++j) {
+        union { bf16x8_t v; unsigned short e[8]; } fb;
+        const unsigned short* xp = xg + (xoff[j] >= 0 ? xoff[j] : 0) + tb;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fb.e[i] = xp[i];
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.v, fb.v, acc[j], 0, 0, 0);
+      }
+    }
+  }
+  // slab of this split: lane holds rows o = 4 kq + i of column kk = 16 j + l16
+  float* P = a.partial + (size_t)split * a.slab;
+#pragma unroll
+  for (int j = 0; j < NT_W; ++j) {
+    const int kk = j * 16 + l16, tap = kk >> 2, c = kk & 3;
+    if (tap < a.k) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) P[((size_t)tap * a.C_out + g * 16 + 4 * kq + i) * IG + c] = acc[j][i];
+    }
+  }
+  if (a.partial_db && l16 == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a.partial_db[(size_t)split * a.slab + g * 16 + 4 * kq + i] = accb[i];
+  }
+}
+
+int grouped_wgrad_splits(int n, int t_out, int groups) {
+  const int tiles = n * vits::ceil_div(t_out, TT);
+  int S = vits::ceil_div(2048, groups);                     // ~512 workgroups of 4 groups
+  if (S > tiles) S = tiles;
+  if (S < 1) S = 1;
+  return S;
+}
+
 int check_geom(int dtype, int n, int t_in, int c_in, int c_out, int k, int stride, int pad, int groups, int* t_out) {
   if (dtype != VITS_DT_BF16) return VITS_E_UNSUPPORTED;
   if (n <= 0 || t_in <= 0 || c_in <= 0 || c_out <= 0 || k <= 0 || stride <= 0 || pad < 0 || groups <= 0) return VITS_E_BADARG;
@@ -346,4 +452,28 @@ extern "C" int vits_grouped_conv_dgrad(int dtype, const void* dy, const void* w,
   } else if (c_out / groups == 16) hipLaunchKernelGGL(grouped_dgrad_kernel<16>, grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL(grouped_dgrad_kernel<4>, grid, dim3(256), 0, s, a);
   return vits::check_launch("vits_grouped_conv_dgrad");
+}
+
+extern "C" size_t vits_grouped_conv_wgrad_workspace(int n, int t_out, int c_out, int k, int groups) {
+  if (n <= 0 || t_out <= 0 || c_out <= 0 || k <= 0 || groups <= 0) return 0;
+  return (size_t)grouped_wgrad_splits(n, t_out, groups) * ((size_t)k * c_out * IG + c_out) * sizeof(float);
+}
+
+extern "C" int vits_grouped_conv_wgrad(int dtype, const void* x, const void* dy, float* dw, float* dbias, void* workspace,
+                                       size_t workspace_bytes, int n, int t_in, int c_in, int c_out, int k, int stride, int pad, int groups,
+                                       int accumulate, vits_wgrad_pending* pending, void* stream) {
+  if (!x || !dy || !dw || !workspace || !pending) return VITS_E_BADARG;
+  int t_out = 0;
+  const int rc = check_geom(dtype, n, t_in, c_in, c_out, k, stride, pad, groups, &t_out);
+  if (rc != VITS_OK) return rc;
+  if (c_out / groups != 16 || k * IG > NT_W * 16) return VITS_E_UNSUPPORTED;
+  const int S = grouped_wgrad_splits(n, t_out, groups);
+  const size_t nd = (size_t)k * c_out * IG, nb = dbias ? (size_t)c_out : 0, slab = nd + nb;
+  if ((size_t)S * slab * sizeof(float) > workspace_bytes) return VITS_E_BADARG;
+  float* ws = static_cast<float*>(workspace);
+  GWArgs a{static_cast<const __bf16*>(x), static_cast<const __bf16*>(dy), ws, dbias ? ws + nd : nullptr,
+           n, t_in, t_out, c_in, c_out, k, stride, pad, S, vits::ceil_div(t_out, TT), slab};
+  hipLaunchKernelGGL(grouped_wgrad_mfma_kernel, dim3(S, groups / 4), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  *pending = vits_wgrad_pending{ws, dw, dbias, nd, nb, slab, S, accumulate ? 1 : 0};
+  return vits::check_launch("vits_grouped_conv_wgrad");
 }

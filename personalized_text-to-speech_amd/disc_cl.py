@@ -79,6 +79,31 @@ def grouped_dgrad(dy, w, res, mg_src, t_in, k, stride, pad, groups):
     return dx
 
 
+def grouped_wgrad(x, dy, k, stride, pad, groups, out, dbias, defer):
+    """Compact dw [k][c_out][4] into `out` and the bias gradient into `dbias` (both float32), second stage deferred to `defer`.
+    Returns None when the layer is not covered (4 output channels per group) or the collector has no slab space left — the caller
+    then takes vits_conv1d_cl_wgrad."""
+    import ctypes
+    _lib.require_cuda(x, dy)
+    n, t_in, c_in = x.shape
+    c_out = dy.size(2)
+    if c_out // groups != 16 or 4 * k > 176:
+        return None
+    assert x.is_contiguous() and dy.is_contiguous() and x.dtype == dy.dtype
+    assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (k, c_out, c_in // groups)
+    assert dbias.dtype == torch.float32 and dbias.is_contiguous() and dbias.numel() == c_out
+    L = _lib.lib()
+    ws = defer.alloc(L.vits_grouped_conv_wgrad_workspace(n, dy.size(1), c_out, k, groups))
+    if ws is None:
+        return None
+    pend = _lib.WgradPending()
+    rc = L.vits_grouped_conv_wgrad(_DT[x.dtype], x.data_ptr(), dy.data_ptr(), out.data_ptr(), dbias.data_ptr(), ws.data_ptr(), ws.numel(),
+                                   n, t_in, c_in, c_out, k, stride, pad, groups, 0, ctypes.addressof(pend), _lib.stream_ptr())
+    _lib.check(rc, "vits_grouped_conv_wgrad")
+    defer.add(pend)
+    return out
+
+
 def first_wgrad(x, dy, dw, p, k, s1, pad, c_out):
     """dw: float32 [k][c_out][8] (column 0 written); returns dbias float32 [c_out]."""
     n, T = x.shape
@@ -269,7 +294,10 @@ class DiscFn(torch.autograd.Function):
                     continue
                 if need_w:
                     db = torch.empty(co, device=xd.device, dtype=torch.float32)
-                    grads[iw] = WG(x_in, dcur, kk, pad=pd, stride=st, out=R[iw].claim_dw(ctx), dbias=db, groups=g, defer=defer)
+                    dw_out = R[iw].claim_dw(ctx)
+                    grads[iw] = grouped_wgrad(cont(x_in), cont(dcur), kk, st, pd, g, dw_out, db, defer) if grouped_direct_ok(dcur, ci, co, kk, st, g) else None
+                    if grads[iw] is None:
+                        grads[iw] = WG(x_in, dcur, kk, pad=pd, stride=st, out=dw_out, dbias=db, groups=g, defer=defer)
                     grads[iw + 1] = db
                 if grouped_direct_ok(dcur, ci, co, kk, st, g):
                     dcur = grouped_dgrad(cont(dcur), R[iw].fwd, None if dprev is None else cont(dprev[lo:]), cont(x_in), x_in.size(1), kk, st, pd, g)

@@ -422,3 +422,21 @@ def test_grouped_direct_kernels_match_torch(pkg, case):
     assert rel(dx, want_dx) < 1e-2
     dx0 = D.grouped_dgrad(dy, dense, None, None, t, k, stride, pad, groups)
     assert rel(dx0, gx.transpose(1, 2)) < 1e-2
+    # weight and bias gradient (compact [k][c_out][4]) through the deferred second stage (16 output channels per group only)
+    defer = pkg.kernels.DeferredReductions(x.device)
+    out, db = torch.empty(k, co, 4, device=DEV), torch.empty(co, device=DEV)
+    got = D.grouped_wgrad(x, dy, k, stride, pad, groups, out, db, defer)
+    if og != 16:
+        assert got is None
+        return
+    assert got is out
+    defer.flush()
+    wf = wc.float().requires_grad_(True)
+    pre2 = F.conv1d(x.float().transpose(1, 2), wf, bias, stride, pad, 1, groups)
+    (gw,) = torch.autograd.grad(pre2, wf, dy.float().transpose(1, 2))
+    assert rel(out, gw.permute(2, 0, 1)) < 2e-3
+    assert rel(db, dy.float().sum((0, 1))) < 2e-3
+    out2, db2 = torch.empty_like(out), torch.empty_like(db)
+    D.grouped_wgrad(x, dy, k, stride, pad, groups, out2, db2, defer)
+    defer.flush()
+    assert torch.equal(out, out2) and torch.equal(db, db2)
