@@ -57,8 +57,11 @@ def grouped_fwd(x, w, bias, k, stride, pad, groups):
     c_out = w.size(1)
     assert x.is_contiguous() and w.is_contiguous() and tuple(w.shape) == (k, c_out, c_in) and w.dtype == x.dtype
     y = torch.empty((n, (t + 2 * pad - k) // stride + 1, c_out), device=x.device, dtype=x.dtype)
+    e0 = _lib.timer.start("vits_grouped_conv")
     rc = _lib.lib().vits_grouped_conv_fwd(_DT[x.dtype], x.data_ptr(), w.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(),
                                           n, t, c_in, c_out, k, stride, pad, groups, SLOPE, _lib.stream_ptr())
+    if e0 is not None:
+        _lib.timer.stop("vits_grouped_conv", e0, (2.0 * y.numel() * 4 * k, 2.0 * (x.numel() + y.numel()) + 2.0 * k * c_out * 4))
     _lib.check(rc, "vits_grouped_conv_fwd")
     return y
 
@@ -72,9 +75,12 @@ def grouped_dgrad(dy, w, res, mg_src, t_in, k, stride, pad, groups):
     for t in (res, mg_src):
         assert t is None or (t.is_contiguous() and tuple(t.shape) == (n, t_in, c_in) and t.dtype == dy.dtype)
     dx = torch.empty((n, t_in, c_in), device=dy.device, dtype=dy.dtype)
+    e0 = _lib.timer.start("vits_grouped_conv")
     rc = _lib.lib().vits_grouped_conv_dgrad(_DT[dy.dtype], dy.data_ptr(), w.data_ptr(), None if res is None else res.data_ptr(),
                                             None if mg_src is None else mg_src.data_ptr(), dx.data_ptr(), n, t_in, c_in, c_out, k, stride,
                                             pad, groups, SLOPE, _lib.stream_ptr())
+    if e0 is not None:
+        _lib.timer.stop("vits_grouped_conv", e0, (2.0 * dy.numel() * 4 * k, 2.0 * (dy.numel() + dx.numel() * (1 + (res is not None) + (mg_src is not None))) + 2.0 * k * c_out * 4))
     _lib.check(rc, "vits_grouped_conv_dgrad")
     return dx
 
@@ -97,8 +103,11 @@ def grouped_wgrad(x, dy, k, stride, pad, groups, out, dbias, defer):
     if ws is None:
         return None
     pend = _lib.WgradPending()
+    e0 = _lib.timer.start("vits_grouped_conv")
     rc = L.vits_grouped_conv_wgrad(_DT[x.dtype], x.data_ptr(), dy.data_ptr(), out.data_ptr(), dbias.data_ptr(), ws.data_ptr(), ws.numel(),
                                    n, t_in, c_in, c_out, k, stride, pad, groups, 0, ctypes.addressof(pend), _lib.stream_ptr())
+    if e0 is not None:
+        _lib.timer.stop("vits_grouped_conv", e0, (2.0 * dy.numel() * 4 * k, 2.0 * (x.numel() + dy.numel()) + 4.0 * out.numel()))
     _lib.check(rc, "vits_grouped_conv_wgrad")
     defer.add(pend)
     return out
