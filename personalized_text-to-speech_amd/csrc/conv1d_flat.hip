@@ -310,7 +310,8 @@ int conv1d_flat_dispatch(const vits_conv_desc& d, int t_out, hipStream_t s) {
     if (d.c_out > 32) return launch_flat<__bf16, 1, 2>(d, t_out, s);                                               // 64 x 64
     return launch_flat<__bf16, 1, 4>(d, t_out, s);                                                                 // 128 x 32
   }
-  if (d.c_out > 64) return launch_flat<float, 2, 2>(d, t_out, s);
+  // fp32 (the DFT products of the mel, 512 rows): 64 x 64 tiles when 64 x 128 would leave most CUs idle
+  if (d.c_out > 64 && ((rows + 63) / 64) * ((d.c_out + 127) / 128) >= 320) return launch_flat<float, 2, 2>(d, t_out, s);
   if (d.c_out > 32) return launch_flat<float, 1, 2>(d, t_out, s);
   return launch_flat<float, 1, 4>(d, t_out, s);
 }
