@@ -332,6 +332,19 @@ int vits_lrelu_mask_bwd(int dtype, const void* dy, const void* y, float slope, c
                         void* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * STFT magnitude -> mel filter bank -> log-clamp in one kernel per direction (csrc/stft_mel.hip), behind the DFT product of
+ * vits_conv1d_cl.  Replaces: mel_processing.py:63-69 `sqrt(re^2 + im^2 + 1e-6)`, :73-82 / :105-111 `log(clamp(mel_basis @ spec, 1e-5))`
+ * and their autograd.
+ *   ri [rows = b * frames][ld] fp32: real parts in columns [0, F), imaginary parts in [Fp, Fp + F); basis [M][F] fp32;
+ *   mel, lin [b][M][frames] fp32 (lin = basis @ magnitude, optional in fwd, required by bwd); clip = 1e-5 in the reference.
+ *   bwd: d ri [rows][ld] (columns outside the two ranges are written as zero).  F <= 2048, M <= 256.
+ * ------------------------------------------------------------------------------------------ */
+int vits_stft_mel_fwd(const float* ri, const float* basis, float* mel, float* lin, int rows, int frames, int F, int Fp, int ld, int M,
+                      float clip, void* stream);
+int vits_stft_mel_bwd(const float* ri, const float* basis, const float* lin, const float* dmel, float* dri, int rows, int frames, int F,
+                      int Fp, int ld, int M, float clip, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Grouped strided convolutions of DiscriminatorS (reference models.py:343-349: 4 input channels per group, 16 or 4 output
  * channels per group, k = 41, stride 4) as direct kernels — csrc/grouped.hip.  bf16 only (VITS_E_UNSUPPORTED otherwise, and
  * for other group shapes: the caller then uses vits_conv1d_cl with `groups`).

@@ -53,6 +53,8 @@ SIGNATURES = {
     "vits_grouped_conv_dgrad": (c_int, [c_int] + [c_void_p] * 5 + [c_int] * 8 + [c_float, c_void_p]),
     "vits_grouped_conv_wgrad_workspace": (c_size_t, [c_int] * 5),
     "vits_grouped_conv_wgrad": (c_int, [c_int] + [c_void_p] * 5 + [c_size_t] + [c_int] * 9 + [c_void_p, c_void_p]),
+    "vits_stft_mel_fwd": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_float, c_void_p]),
+    "vits_stft_mel_bwd": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_float, c_void_p]),
     "vits_disc_first_rows": (c_int, [c_int] * 5),
     "vits_disc_first_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_float, c_void_p]),
     "vits_disc_first_wgrad_workspace": (c_size_t, [c_int] * 7),

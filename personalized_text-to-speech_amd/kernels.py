@@ -229,21 +229,16 @@ def _dft_operand(n_fft, hop, window):
     return op
 
 
-def stft_magnitude(y, n_fft, hop, win, window):
-    """reflect-pad (n_fft-hop)/2, framed windowed real DFT, sqrt(re^2+im^2+1e-6)
-    (reference mel_processing.py:63-69).  y [b, t] -> [b, n_fft/2+1, frames].
-
-    On the GPU the framed DFT is an exact-fp32 matrix-core product: the padded signal is viewed as rows of
-    `hop` samples, a frame is n_fft/hop consecutive rows, so the STFT is vits_conv1d_cl with k = n_fft/hop taps
-    over a windowed cos/sin basis (fp32 MFMA = fmaf chain).  Falls back to torch.stft (rocFFT) when
-    hop does not divide n_fft or the window is not n_fft long."""
+def _stft_ri(y, n_fft, hop, win, window):
+    """The framed windowed real DFT of the reflect-padded signal as an exact-fp32 matrix-core product: the padded signal is
+    viewed as rows of `hop` samples, a frame is n_fft/hop consecutive rows, so the STFT is vits_conv1d_cl with k = n_fft/hop
+    taps over a windowed cos/sin basis (fp32 MFMA = fmaf chain).  -> (ri [b, frames, 2*Fp] fp32: re | im, F, Fp), or None when
+    hop does not divide n_fft / the window is not n_fft long / the signal is on the host (the caller then uses torch.stft)."""
+    if not (y.is_cuda and n_fft % hop == 0 and win == n_fft and hop % 4 == 0):
+        return None
+    from . import wn_cl
     pad = int((n_fft - hop) / 2)
     yp = F.pad(y.unsqueeze(1), (pad, pad), mode="reflect").squeeze(1)
-    if not (y.is_cuda and n_fft % hop == 0 and win == n_fft and hop % 4 == 0):
-        spec = torch.stft(yp, n_fft, hop_length=hop, win_length=win, window=window, center=False,
-                          normalized=False, onesided=True, return_complex=True)
-        return torch.sqrt(spec.real.pow(2) + spec.imag.pow(2) + 1e-6)
-    from . import wn_cl
     b, tp = yp.shape
     taps = n_fft // hop
     frames = (tp - n_fft) // hop + 1
@@ -255,9 +250,66 @@ def stft_magnitude(y, n_fft, hop, win, window):
     x = yp[:, :need].reshape(b, rows, hop)
     op = _dft_operand(n_fft, hop, window.float())
     ri = wn_cl.conv_cl(x, op, dtype=torch.float32)                     # [b, frames, 2*Fp]
-    F_, Fp = n_fft // 2 + 1, op.size(1) // 2
+    return ri, n_fft // 2 + 1, op.size(1) // 2
+
+
+def stft_magnitude(y, n_fft, hop, win, window):
+    """reflect-pad (n_fft-hop)/2, framed windowed real DFT, sqrt(re^2+im^2+1e-6)
+    (reference mel_processing.py:63-69).  y [b, t] -> [b, n_fft/2+1, frames].  On the GPU the DFT is _stft_ri's matrix-core
+    product; otherwise torch.stft (rocFFT / host)."""
+    got = _stft_ri(y, n_fft, hop, win, window)
+    if got is None:
+        pad = int((n_fft - hop) / 2)
+        yp = F.pad(y.unsqueeze(1), (pad, pad), mode="reflect").squeeze(1)
+        spec = torch.stft(yp, n_fft, hop_length=hop, win_length=win, window=window, center=False,
+                          normalized=False, onesided=True, return_complex=True)
+        return torch.sqrt(spec.real.pow(2) + spec.imag.pow(2) + 1e-6)
+    ri, F_, Fp = got
     mag = torch.sqrt(ri[..., :F_].pow(2) + ri[..., Fp:Fp + F_].pow(2) + 1e-6)
     return mag.transpose(1, 2)
+
+
+class _StftMel(torch.autograd.Function):
+    """log(clamp(basis @ sqrt(re^2 + im^2 + 1e-6), clip)) of a DFT product ri [b, frames, 2*Fp] -> [b, M, frames]
+    (csrc/stft_mel.hip: one launch per direction; reference mel_processing.py:63-69, 73-82)."""
+
+    @staticmethod
+    def forward(ctx, ri, basis, F_, Fp, clip):
+        _lib.require_cuda(ri, basis)
+        assert ri.dtype == torch.float32 and ri.is_contiguous() and basis.dtype == torch.float32 and basis.is_contiguous()
+        b, frames, ld = ri.shape
+        M = basis.size(0)
+        assert basis.size(1) == F_ and ld >= 2 * Fp
+        mel = torch.empty((b, M, frames), device=ri.device, dtype=torch.float32)
+        lin = torch.empty_like(mel)
+        rc = _lib.lib().vits_stft_mel_fwd(ri.data_ptr(), basis.data_ptr(), mel.data_ptr(), lin.data_ptr(), b * frames, frames, F_, Fp, ld, M,
+                                          float(clip), _lib.stream_ptr())
+        _lib.check(rc, "vits_stft_mel_fwd")
+        ctx.save_for_backward(ri, basis, lin)
+        ctx.geom = (F_, Fp, float(clip))
+        return mel
+
+    @staticmethod
+    def backward(ctx, dmel):
+        ri, basis, lin = ctx.saved_tensors
+        F_, Fp, clip = ctx.geom
+        b, frames, ld = ri.shape
+        dmel = dmel.float().contiguous()
+        dri = torch.empty_like(ri)
+        rc = _lib.lib().vits_stft_mel_bwd(ri.data_ptr(), basis.data_ptr(), lin.data_ptr(), dmel.data_ptr(), dri.data_ptr(), b * frames, frames,
+                                          F_, Fp, ld, basis.size(0), clip, _lib.stream_ptr())
+        _lib.check(rc, "vits_stft_mel_bwd")
+        return dri, None, None, None, None
+
+
+def stft_mel(y, n_fft, hop, win, window, basis, clip=1e-5):
+    """mel_spectrogram of the reference (mel_processing.py:85-112) on the GPU: DFT product + ONE fused magnitude / filter-bank /
+    log-clamp launch (and one for its backward).  None when the DFT product does not apply (the caller composes torch ops)."""
+    got = _stft_ri(y, n_fft, hop, win, window)
+    if got is None:
+        return None
+    ri, F_, Fp = got
+    return _StftMel.apply(ri.contiguous(), basis.float().contiguous(), F_, Fp, clip)
 
 
 # ================================================================================================

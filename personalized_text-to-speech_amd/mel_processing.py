@@ -112,5 +112,13 @@ def _mel(spec, basis):
 
 def mel_spectrogram_torch(y, n_fft, num_mels, sampling_rate, hop_size, win_size, fmin, fmax, center=False):
     # reference mel_processing.py:85-112 (computes in fp32: `y.float()` at :104)
-    spec = spectrogram_torch(y.float(), n_fft, sampling_rate, hop_size, win_size, center)
+    y = y.float()
+    if y.is_cuda and not center:
+        # DFT product + one fused magnitude / mel filter bank / log-clamp launch (csrc/stft_mel.hip), fp32 like the reference
+        basis = _basis(sampling_rate, n_fft, num_mels, fmin, fmax, y.dtype, y.device)
+        with torch.autocast("cuda", enabled=False):
+            mel = kernels.stft_mel(y, n_fft, hop_size, win_size, _window(win_size, y.dtype, y.device), basis)
+        if mel is not None:
+            return mel
+    spec = spectrogram_torch(y, n_fft, sampling_rate, hop_size, win_size, center)
     return _mel(spec, _basis(sampling_rate, n_fft, num_mels, fmin, fmax, spec.dtype, spec.device))

@@ -141,3 +141,31 @@ def test_fused_lsgan_losses_match_reference_formulas(pkg, dtype):
     assert all(abs(float(a) - float(b)) <= 1e-5 * abs(float(b)) for a, b in zip(fused[1] + fused[2], plain[1] + plain[2]))
     gl_f, gl_p = losses.generator_loss(gs), losses.generator_loss(list(gs))
     assert abs(float(gl_f[0]) - float(gl_p[0])) <= 1e-5 * abs(float(gl_p[0])) and len(gl_f[1]) == 6
+
+
+def test_fused_stft_mel_epilogue_matches_torch(pkg):
+    """csrc/stft_mel.hip: sqrt(re^2 + im^2 + 1e-6) -> mel filter bank -> log(clamp(., 1e-5)) and its backward against the same
+    chain of torch ops in fp32 (incl. a silent frame and an all-zero filter: the clamp's dead region), bitwise reproducible."""
+    import torch
+    K = pkg.kernels
+    torch.manual_seed(5)
+    b, frames, F_, Fp, M = 3, 7, 513, 520, 80
+    ri = torch.randn(b, frames, 2 * Fp, device="cuda") * 3
+    ri[1, 2] = 0.0                                                   # silence: magnitude 1e-3 everywhere
+    basis = torch.rand(M, F_, device="cuda") * (torch.rand(M, F_, device="cuda") < 0.05)
+    basis[7] = 0.0                                                   # lin = 0 < clip
+    basis[9] *= 1e-6
+    ri_a = ri.clone().requires_grad_(True)
+    mel = K._StftMel.apply(ri_a, basis, F_, Fp, 1e-5)
+    ri_b = ri.clone().requires_grad_(True)
+    mag = torch.sqrt(ri_b[..., :F_].pow(2) + ri_b[..., Fp:Fp + F_].pow(2) + 1e-6)
+    want = torch.log(torch.clamp(torch.matmul(basis, mag.transpose(1, 2)), min=1e-5))
+    assert tuple(mel.shape) == (b, M, frames)
+    assert float((mel - want).abs().max()) < 1e-4 * float(want.abs().max())
+    g = torch.randn_like(want)
+    mel.backward(g)
+    want.backward(g)
+    assert float((ri_a.grad - ri_b.grad).abs().max()) < 1e-4 * float(ri_b.grad.abs().max())
+    assert float(ri_a.grad[..., F_:Fp].abs().max()) == 0.0 and float(ri_a.grad[..., Fp + F_:].abs().max()) == 0.0
+    mel2 = K._StftMel.apply(ri.clone(), basis, F_, Fp, 1e-5)
+    assert torch.equal(mel.detach(), mel2)
