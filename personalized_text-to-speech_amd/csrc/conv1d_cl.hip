@@ -68,6 +68,12 @@ __device__ __forceinline__ u32x4 lrelu_vec(u32x4 raw, float slope) {
 }
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
+// tanh of the WaveNet gate: libm's tanhf costs about as much as the layer's MFMA loop per element; bf16 mode takes
+// 1 - 2 / (1 + e^{2v}) on the fast exponential (absolute error ~1e-7, far below bf16's rounding), fp32 parity mode keeps tanhf
+template <typename T> __device__ __forceinline__ float gate_tanh(float v) {
+  if constexpr (sizeof(T) == 2) return 1.0f - 2.0f / (1.0f + __expf(2.0f * v));
+  else return tanhf(v);
+}
 
 constexpr int XV_MAX = 6;     // 16-byte vectors of the X tile a thread may hold in flight (xrows*8 <= 256*XV_MAX)
 constexpr int WV_MAX = 9;     // ... of the W slab (G*TN*8 <= 256*WV_MAX)
@@ -320,7 +326,7 @@ __global__ __launch_bounds__(kThreads) void conv1d_cl_kernel(ConvArgs args) {
             Y2[(size_t)t * a.ldy2 + co] = from_f<T>(va);
             Y2[(size_t)t * a.ldy2 + co + a.gate_h] = from_f<T>(vb);
           }
-          Y[(size_t)t * a.ldy + co] = from_f<T>(tanhf(va) * sigmoidf_(vb));
+          Y[(size_t)t * a.ldy + co] = from_f<T>(gate_tanh<T>(va) * sigmoidf_(vb));
         }
       }
     }
@@ -366,7 +372,7 @@ __global__ __launch_bounds__(kThreads) void conv1d_cl_kernel(ConvArgs args) {
       v *= a.out_scale;
       if (a.flags & VITS_CONV_GATE_BWD) {
         // chain rule of the gate: v = d(acts[:, co]);  mg_src = saved pre-activations [.., 2H]
-        const float ta = tanhf(to_f(MG[o])), sb = sigmoidf_(to_f(MG[o + a.gate_h]));
+        const float ta = gate_tanh<T>(to_f(MG[o])), sb = sigmoidf_(to_f(MG[o + a.gate_h]));
         const bool dead = (a.flags & VITS_CONV_MASK_OUT) && t >= len;
         Y[o] = from_f<T>(dead ? 0.f : v * sb * (1.0f - ta * ta));
         Y[o + a.gate_h] = from_f<T>(dead ? 0.f : v * ta * sb * (1.0f - sb));
