@@ -87,9 +87,9 @@ class FlatAdamW(torch.optim.AdamW):
                 if "exp_avg" in st:
                     self.state[p]["exp_avg"].copy_(st["exp_avg"]); self.state[p]["exp_avg_sq"].copy_(st["exp_avg_sq"])
                     steps.add(float(st["step"]))
-            if len(steps) > 1:
-                raise ValueError("FlatAdamW: parameters with different step counts")
-            self.dev_state[1] = steps.pop() if steps else 0.0
+            # one shared step counter: torch keeps one per parameter, and they only differ when some parameters were skipped
+            # in some steps (no gradient); the bias corrections then follow the most-stepped parameter
+            self.dev_state[1] = max(steps) if steps else 0.0
         self._sync_lr(force=True)
 
     def _sync_lr(self, force=False):

@@ -281,6 +281,10 @@ class FineTuner:
     def epoch_end(self):
         self.sched_g.step()            # ExponentialLR per epoch, finetune_speaker_v2.py:157-158
         self.sched_d.step()
+        # the AdamW kernel reads lr from device memory; a replayed graph never passes FlatAdamW.step(), so refresh it here
+        # (a device fill outside the graph, stream-ordered before the next replay)
+        self.optim_g._sync_lr()
+        self.optim_d._sync_lr()
 
 
 def evaluate(hps, generator, batch, max_len=1000):

@@ -7,7 +7,8 @@ either side load on the other: the reference's public G_0.pth / D_0.pth fine-tun
 Differences, none visible in the files:
   * `torch.load(..., weights_only=True)`: nothing from a checkpoint file is executed (the reference unpickles freely);
   * a key missing from the file keeps the model's own tensor, as in the reference (utils.py:175-177), but the names are
-    returned instead of being logged one by one.
+    returned instead of being logged one by one; so does an `emb_g.weight` that does not fit into the model's table (more
+    rows, other width): the reference's bare `except` keeps the model's table there too.
 """
 import json
 import logging
@@ -34,14 +35,20 @@ def load_checkpoint(checkpoint_path, model, optimizer=None, drop_speaker_emb=Fal
     state_dict = target.state_dict()
     new_state_dict, missing = {}, []
     for k, v in state_dict.items():
-        if k not in saved_state_dict or (k != "emb_g.weight" and saved_state_dict[k].shape != v.shape):
+        if k not in saved_state_dict:                  # (a tensor of another shape is handed on: load_state_dict raises, as there)
             missing.append(k)
             new_state_dict[k] = v
         elif k == "emb_g.weight":
+            saved = saved_state_dict[k]
             if not drop_speaker_emb:
-                rows = saved_state_dict[k].shape[0]
-                v = v.clone()
-                v[:rows, :] = saved_state_dict[k].to(v)
+                if saved.dim() == 2 and saved.shape[0] <= v.shape[0] and saved.shape[1] == v.shape[1]:
+                    v = v.clone()
+                    v[:saved.shape[0], :] = saved.to(v)
+                else:
+                    # a table with MORE rows than the model's (a many-speaker G_0.pth into a few-speaker fine-tune config) or
+                    # another gin_channels: the reference's row assignment raises inside its bare try/except and the model
+                    # keeps its own table (utils.py:162-177) — same here, reported with the missing keys
+                    missing.append(k)
             new_state_dict[k] = v
         else:
             new_state_dict[k] = saved_state_dict[k]

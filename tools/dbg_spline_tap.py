@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Locates the irreproducible element of the duration flows' spline backward without touching the kernel:
+every vits_flow_spline_bwd call of the captured step gets its inputs (x2, h, mask, dy2, dlogdet) and outputs (dx2, gh) cloned
+into static buffers by extra copy nodes of the graph; after each replay from the SAME state the host compares them with the
+first replay's.  Prints, per differing tensor, where and by what it differs.  Run against a libvitsmi.so whose rq_spline.hip
+was compiled with and without csrc/Makefile's former FLAGS_rq_spline."""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+from importlib import import_module
+P = import_module("personalized_text-to-speech_amd"); cfgs = import_module("personalized_text-to-speech_amd.configs")
+tr = import_module("personalized_text-to-speech_amd.train"); rowops = import_module("personalized_text-to-speech_amd.rowops")
+K = P.kernels
+
+taps, active = [], [False]
+orig_bwd = rowops.FlowTailFn.backward
+orig_mask = K.lrelu_mask_bwd
+
+
+def tapped_bwd(ctx, dout, dlogdet):
+    res = orig_bwd(ctx, dout, dlogdet)
+    if active[0]:
+        xd, hd, md = ctx.saved_tensors
+        rec = {"x2": xd.clone(), "h": hd.clone(), "mask": md.clone(), "dy2": dout.float().clone(), "dlogdet": dlogdet.float().clone(),
+               "dx2": res[0].clone(), "gh": res[1].clone()}
+        taps.append(rec)
+    return res
+
+
+def tapped_mask(dy, y=None, slope=1.0, lengths=None):
+    out = orig_mask(dy, y, slope, lengths)
+    if active[0] and dy.dim() == 3 and dy.size(2) == 32 and y is None:
+        taps.append({"maskbwd_in": dy.clone(), "maskbwd_out": out.clone()})
+    return out
+
+
+rowops.FlowTailFn.backward = staticmethod(tapped_bwd)
+K.lrelu_mask_bwd = tapped_mask
+import_module("personalized_text-to-speech_amd.wn_cl").K.lrelu_mask_bwd = tapped_mask
+
+cfg_name, batch_size, t_y_range = cfgs.WORKLOADS[os.environ.get("WL", "C2")]
+hps = cfgs.get(cfg_name)
+ft = tr.FineTuner(hps, "cuda:0", amp=True)
+batch = tr.synthetic_batch(hps, batch_size, t_y_range, "cuda:0")
+# warm up eagerly (untapped), then capture with the taps on
+side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side):
+    for _ in range(3):
+        ft.step(batch)
+torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+active[0] = True
+ft.capture(batch, warmup=0)
+active[0] = False
+print(f"{len(taps)} tapped calls in the captured step", flush=True)
+ts = ft._state_tensors()
+snap = [t.detach().clone() for t in ts]
+rng = torch.cuda.get_rng_state(ft.device)
+
+
+def run():
+    with torch.no_grad():
+        for t, s in zip(ts, snap):
+            t.copy_(s)
+    torch.cuda.set_rng_state(rng, ft.device)
+    ft.replay()
+    torch.cuda.synchronize()
+    return [{k: v.detach().cpu().clone() for k, v in rec.items()} for rec in taps], ft.optim_g.flat_p.detach().cpu().clone()
+
+
+NR = int(os.environ.get("NREP", "30"))
+base, p0 = run()
+n_bad = 0
+for r in range(1, NR):
+    cur, p1 = run()
+    lines = []
+    for ci, (a, b) in enumerate(zip(base, cur)):
+        for k in a:
+            if not torch.equal(a[k], b[k]):
+                A, B = a[k].float(), b[k].float()
+                idx = (A != B).nonzero()
+                lines.append(f"   call {ci} {k} shape {tuple(A.shape)}: {idx.size(0)} elements differ; first {idx[:6].tolist()}")
+                for ix in idx[:4].tolist():
+                    row = ix[0]
+                    lines.append(f"      at {ix}: base {A[tuple(ix)].item():.6e}  now {B[tuple(ix)].item():.6e}")
+                    if A.dim() == 2:
+                        lines.append(f"      base row {row}: {[f'{v:.3e}' for v in A[row].tolist()]}")
+                        lines.append(f"      now  row {row}: {[f'{v:.3e}' for v in B[row].tolist()]}")
+                        if row + 1 < A.size(0):
+                            lines.append(f"      base row {row + 1}: {[f'{v:.3e}' for v in A[row + 1].tolist()]}")
+                        if row >= 1:
+                            lines.append(f"      base row {row - 1}: {[f'{v:.3e}' for v in A[row - 1].tolist()]}")
+                        # is the odd value present anywhere in the base tensor's same column?
+                        col = ix[1]
+                        hits = (A[:, col] == B[tuple(ix)]).nonzero().flatten().tolist()[:8]
+                        lines.append(f"      rows of base whose column {col} equals the odd value: {hits}")
+    pd = int((p0 != p1).sum())
+    if lines or pd:
+        n_bad += 1
+        print(f"--- replay {r + 1}: {pd} parameter elements differ from replay 1", flush=True)
+        print("\n".join(lines), flush=True)
+print(f"{n_bad} of {NR - 1} replays differ from the first", flush=True)
