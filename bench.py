@@ -56,7 +56,7 @@ def cpu_baseline(cfgs, seconds_budget=40.0, threads=16):
     del g, d
     opt_g = torch.optim.AdamW([v for v in sd_g.values() if v.requires_grad], hps.train.learning_rate, betas=hps.train.betas, eps=hps.train.eps)
     opt_d = torch.optim.AdamW(list(sd_d.values()), hps.train.learning_rate, betas=hps.train.betas, eps=hps.train.eps)
-    batch = tr.synthetic_batch(hps, B, t_y, "cpu",
+    batch = tr.synthetic_batch(hps, B, t_y, "cpu", frames_per_token=8,          # T_y = (400, 320), T_x = (101, 81)
                                spec_fn=lambda w: O.spectrogram(w, hps.data.filter_length, hps.data.hop_length, hps.data.win_length))
     x, spec = batch[0], batch[2]
     hp = dict(hps.data); hp.update(hps.train)
@@ -85,7 +85,7 @@ def cpu_baseline(cfgs, seconds_budget=40.0, threads=16):
     except Exception:
         pass
     rng = np.random.default_rng(0)
-    for tag, (bb, ty, tx) in dict(c1=(2, 400, 161), c3=(64, 800, 321)).items():
+    for tag, (bb, ty, tx) in dict(c1=(2, 400, 101), c3=(64, 800, 321)).items():
         nc = rng.standard_normal((bb, ty, tx)).astype(np.float32)
         t_ys, t_xs = np.full(bb, ty, np.int32), np.full(bb, tx, np.int32)
         fn(nc, t_ys, t_xs)
@@ -94,7 +94,7 @@ def cpu_baseline(cfgs, seconds_budget=40.0, threads=16):
             t0 = time.perf_counter(); fn(nc, t_ys, t_xs); reps.append(time.perf_counter() - t0)
         dp[tag] = dict(shape=[bb, ty, tx], ms=statistics.median(reps) * 1e3, Mcell_per_s=bb * ty * tx / statistics.median(reps) / 1e6)
     return dict(value=B * hps.train.segment_size / step_s, unit="samples/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"C1 shapes (finetune_speaker.json, batch {B}, T_y=(400,320), T_x={T_x}): oracle torch-cpu fp32 step + alignment DP, "
+                sample=f"C1 shapes (finetune_speaker.json, batch {B}, T_y=(400,320), T_x=({T_x},{int(batch[1][1])})): oracle torch-cpu fp32 step + alignment DP, "
                        f"median of {len(timed)} step(s) after 1 warm-up, {step_s:.2f} s/step, {t_total:.1f} s in all",
                 alignment_dp=dict(cores=1, kind=kind, **dp))
 

@@ -178,6 +178,48 @@ int vits_conv1d_cl_wgrad_deferred(const vits_wgrad_desc* desc, void* stream, vit
 int vits_wgrad_reduce_pending(const vits_wgrad_pending* list, int count, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * One WaveNet layer per launch (csrc/wn_layer.hip).
+ *
+ * Replaces: one iteration of modules.WN.forward's loop (modules.py:157-176) incl. the TorchScript gate
+ *           commons.fused_add_tanh_sigmoid_multiply (commons.py:103-110) and, for the backward call, autograd's chain through it:
+ *     x_in = in_layers[i](x);  acts = tanh((x_in + g_l)[:, :H]) * sigmoid((x_in + g_l)[:, H:]);
+ *     res_skip = res_skip_layers[i](acts);  x = (x + res_skip[:, :H]) * x_mask;  output += res_skip[:, H:]
+ *   (last layer: res_skip has H rows, all of them skip).  Channels-last [b][t][c]; rows t >= lengths[b] of x must be zero.
+ *   forward : x [b][t][H];  w_in [k][2H][H], w_rs [1][2H | H][H] (dtype of x; the weight arena's forward operands), b_in / b_rs
+ *             float32, cond float32 [b][2H] (this layer's slice of cond_layer(g)) or NULL;
+ *             pre [b][t][2H] (pre-activations incl. bias and cond; optional) and acts [b][t][H] (optional) are the backward's
+ *             saved tensors;  h_out [b][t][H] = (x + res) * mask (NULL for the last layer);  skip [b][t][H] (+)= skip * mask.
+ *   backward: dcat [b][t][2H] = [d_h | d_o] (d_o = the masked gradient of the stack's output, the same for every layer; the last
+ *             layer passes d_o alone, lddcat = its row pitch);  w_rs_t [1][H][2H | H] and w_in_t [k][H][2H] (tap-reversed) are the
+ *             arena's data-gradient operands;  d_pre [b][t][2H] = gate'(pre) * (dcat . W_rs), masked — written for the weight
+ *             gradients;  d_h_out [b][t][H] = d_h + conv^T(d_pre; W_in), masked (last layer: no d_h term).
+ *   dtype VITS_DT_BF16 or VITS_DT_F32 (exact fp32 products); H % 16 == 0, H <= 192, k odd.
+ *   Returns VITS_E_UNSUPPORTED for other shapes (the caller then composes the layer from vits_conv1d_cl launches).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct vits_wn_layer_desc {
+  int32_t dtype, b, t, h, k, dil;
+  int32_t last;             /* the stack's last layer: res_skip has H rows (skip only)                         */
+  int32_t accumulate;       /* skip += (0: skip =)                                                             */
+  int32_t ldx, ldh, ldskip, ldacts, ldpre;      /* row pitches in elements; 0 = dense                         */
+  const void* x;  const void* w_in;  const float* b_in;  const float* cond;
+  const void* w_rs;  const float* b_rs;
+  void* pre;  void* acts;  void* h_out;  void* skip;
+  const int32_t* lengths;
+} vits_wn_layer_desc;
+int vits_wn_layer_fwd(const vits_wn_layer_desc* desc, void* stream);
+
+typedef struct vits_wn_layer_bwd_desc {
+  int32_t dtype, b, t, h, k, dil;
+  int32_t last;             /* the stack's last layer: no d_h input, W_rs^T has H columns                       */
+  int32_t ld_dh, ld_do, ldpre, lddpre, ldout;   /* row pitches in elements; 0 = dense                          */
+  const void* d_h;  const void* d_o;  const void* pre;
+  const void* w_rs_t;  const void* w_in_t;
+  void* d_pre;  void* d_h_out;
+  const int32_t* lengths;
+} vits_wn_layer_bwd_desc;
+int vits_wn_layer_bwd(const vits_wn_layer_bwd_desc* desc, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Channels-last ConvTranspose1d = 1x1 matrix-core product + overlap-add.
  *
  * Replaces: models.py:277 `self.ups[i](x)` (weight-normed torch.nn.ConvTranspose1d(c_in, c_out, k,

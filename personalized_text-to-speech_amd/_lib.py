@@ -10,7 +10,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvitsmi.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 c_int = ctypes.c_int
 c_void_p = ctypes.c_void_p
@@ -49,6 +49,8 @@ SIGNATURES = {
     "vits_conv1d_cl_wgrad_deferred": (c_int, [c_void_p, c_void_p, c_void_p]),
     "vits_wgrad_reduce_pending": (c_int, [c_void_p, c_int, c_void_p]),
     "vits_conv1d_cl": (c_int, [c_void_p, c_void_p]),
+    "vits_wn_layer_fwd": (c_int, [c_void_p, c_void_p]),
+    "vits_wn_layer_bwd": (c_int, [c_void_p, c_void_p]),
     "vits_grouped_conv_fwd": (c_int, [c_int] + [c_void_p] * 4 + [c_int] * 8 + [c_float, c_void_p]),
     "vits_grouped_conv_dgrad": (c_int, [c_int] + [c_void_p] * 5 + [c_int] * 8 + [c_float, c_void_p]),
     "vits_grouped_conv_wgrad_workspace": (c_size_t, [c_int] * 5),
@@ -97,6 +99,18 @@ class ConvDesc(ctypes.Structure):
                [("w_batch_stride", ctypes.c_int64)] + \
                [(n, c_float) for n in ("in_slope", "mg_slope", "out_scale", "out_slope")] + \
                [(n, c_void_p) for n in ("x", "w", "bias", "bias_b", "res", "mg_src", "y", "y2", "lengths")]
+
+
+class WnLayerDesc(ctypes.Structure):
+    """vits_wn_layer_desc of include/vitsmi.h"""
+    _fields_ = [(n, ctypes.c_int32) for n in ("dtype", "b", "t", "h", "k", "dil", "last", "accumulate", "ldx", "ldh", "ldskip", "ldacts", "ldpre")] + \
+               [(n, c_void_p) for n in ("x", "w_in", "b_in", "cond", "w_rs", "b_rs", "pre", "acts", "h_out", "skip", "lengths")]
+
+
+class WnLayerBwdDesc(ctypes.Structure):
+    """vits_wn_layer_bwd_desc of include/vitsmi.h"""
+    _fields_ = [(n, ctypes.c_int32) for n in ("dtype", "b", "t", "h", "k", "dil", "last", "ld_dh", "ld_do", "ldpre", "lddpre", "ldout")] + \
+               [(n, c_void_p) for n in ("d_h", "d_o", "pre", "w_rs_t", "w_in_t", "d_pre", "d_h_out", "lengths")]
 
 
 class PrepEntry(ctypes.Structure):
@@ -175,6 +189,7 @@ class VitsKernelError(RuntimeError):
 
 
 _CODES = {-1: "VITS_E_BADARG", -2: "VITS_E_UNSUPPORTED", -3: "VITS_E_LAUNCH"}
+E_UNSUPPORTED = -2
 
 
 def check(rc, what):

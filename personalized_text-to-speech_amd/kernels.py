@@ -5,8 +5,8 @@ Each op is either
            wrapped in a torch.autograd.Function where it needs a backward; or
   * ROCm — a composition of PyTorch-ROCm device ops (element-wise glue, rocBLAS for two small matmuls, the fused
            AdamW).  DESIGN.md §4 lists which is which; `BACKENDS` below is the same table in code, and bench.py
-           prints it.  The library convolutions behind `conv1d` / `conv_transpose1d` here are only reached by the
-           A/B switches (VITS_DISC_P / VITS_DISC_S = library) and by generic module calls outside the hot path.
+           prints it.  `conv1d` / `conv_transpose1d` here are CPU-side utilities for generic module calls (state_dict and
+           shape helpers, the host-logic tests): they RAISE on GPU tensors — no library convolution is on the hot path.
 There is no CPU implementation of the HIP ops: they raise on non-GPU tensors.
 """
 import math
@@ -229,7 +229,7 @@ def _dft_operand(n_fft, hop, window):
     return op
 
 
-def _stft_ri(y, n_fft, hop, win, window):
+def _stft_ri(y, n_fft, hop, win, window, prepadded=False):
     """The framed windowed real DFT of the reflect-padded signal as an exact-fp32 matrix-core product: the padded signal is
     viewed as rows of `hop` samples, a frame is n_fft/hop consecutive rows, so the STFT is vits_conv1d_cl with k = n_fft/hop
     taps over a windowed cos/sin basis (fp32 MFMA = fmaf chain).  -> (ri [b, frames, 2*Fp] fp32: re | im, F, Fp), or None when
@@ -238,7 +238,7 @@ def _stft_ri(y, n_fft, hop, win, window):
         return None
     from . import wn_cl
     pad = int((n_fft - hop) / 2)
-    yp = F.pad(y.unsqueeze(1), (pad, pad), mode="reflect").squeeze(1)
+    yp = y if prepadded else F.pad(y.unsqueeze(1), (pad, pad), mode="reflect").squeeze(1)
     b, tp = yp.shape
     taps = n_fft // hop
     frames = (tp - n_fft) // hop + 1
@@ -253,14 +253,14 @@ def _stft_ri(y, n_fft, hop, win, window):
     return ri, n_fft // 2 + 1, op.size(1) // 2
 
 
-def stft_magnitude(y, n_fft, hop, win, window):
+def stft_magnitude(y, n_fft, hop, win, window, prepadded=False):
     """reflect-pad (n_fft-hop)/2, framed windowed real DFT, sqrt(re^2+im^2+1e-6)
     (reference mel_processing.py:63-69).  y [b, t] -> [b, n_fft/2+1, frames].  On the GPU the DFT is _stft_ri's matrix-core
     product; otherwise torch.stft (rocFFT / host)."""
-    got = _stft_ri(y, n_fft, hop, win, window)
+    got = _stft_ri(y, n_fft, hop, win, window, prepadded)
     if got is None:
         pad = int((n_fft - hop) / 2)
-        yp = F.pad(y.unsqueeze(1), (pad, pad), mode="reflect").squeeze(1)
+        yp = y if prepadded else F.pad(y.unsqueeze(1), (pad, pad), mode="reflect").squeeze(1)
         spec = torch.stft(yp, n_fft, hop_length=hop, win_length=win, window=window, center=False,
                           normalized=False, onesided=True, return_complex=True)
         return torch.sqrt(spec.real.pow(2) + spec.imag.pow(2) + 1e-6)
@@ -382,6 +382,85 @@ def conv1d_cl_raw(x, w, bias=None, bias_b=None, res=None, mg_src=None, out=None,
     return out
 
 
+def wn_layer_fwd(x, w_in, b_in, cond, w_rs, b_rs, lengths, dil, skip, accumulate, last, pre=None, acts=None):
+    """One WaveNet layer in one launch (csrc/wn_layer.hip, vits_wn_layer_fwd; reference modules.py:157-176): x [b,t,H] with rows
+    >= lengths zero, w_in [k][2H][H] / w_rs [1][2H|H][H] in x's dtype, b_in / b_rs fp32, cond fp32 [b][2H] or None.
+    Writes pre [b,t,2H] / acts [b,t,H] when given, accumulates the skip half into `skip`, returns h_out (None for the last
+    layer).  Returns NotImplemented when the kernel does not take the shape (the caller composes the layer from conv launches)."""
+    _lib.require_cuda(x, w_in, w_rs, skip)
+    b, t, H = x.shape
+    k = w_in.size(0)
+    if H % 16 != 0 or H > 192 or k % 2 == 0:
+        return NotImplemented
+    assert w_in.dtype == x.dtype and w_rs.dtype == x.dtype and w_in.is_contiguous() and w_rs.is_contiguous()
+    assert tuple(w_in.shape) == (k, 2 * H, H) and tuple(w_rs.shape) == (1, H if last else 2 * H, H), (tuple(w_in.shape), tuple(w_rs.shape))
+    for tns in (b_in, b_rs, cond):
+        assert tns is None or (tns.dtype == torch.float32 and tns.is_contiguous())
+    assert cond is None or tuple(cond.shape) == (b, 2 * H)
+    assert lengths is None or lengths.dtype == torch.int32
+    h_out = None if last else torch.empty((b, t, H), device=x.device, dtype=x.dtype)
+    for tns, c in ((pre, 2 * H), (acts, H), (skip, H)):
+        assert tns is None or (tns.dtype == x.dtype and tuple(tns.shape) == (b, t, c))
+    p = lambda v: None if v is None else v.data_ptr()
+    d = _lib.WnLayerDesc(dtype=_DT[x.dtype], b=b, t=t, h=H, k=k, dil=dil, last=int(bool(last)), accumulate=int(bool(accumulate)),
+                         ldx=_rows(x, "x"), ldh=H, ldskip=_rows(skip, "skip"), ldacts=0 if acts is None else _rows(acts, "acts"),
+                         ldpre=0 if pre is None else _rows(pre, "pre"),
+                         x=x.data_ptr(), w_in=w_in.data_ptr(), b_in=p(b_in), cond=p(cond), w_rs=w_rs.data_ptr(), b_rs=p(b_rs),
+                         pre=p(pre), acts=p(acts), h_out=p(h_out), skip=skip.data_ptr(), lengths=p(lengths))
+    import ctypes
+    e0 = _lib.timer.start("vits_wn_layer_fwd")
+    rc = _lib.lib().vits_wn_layer_fwd(ctypes.addressof(d), _lib.stream_ptr())
+    if e0 is not None:
+        es = x.element_size()
+        c_rs = H if last else 2 * H
+        _lib.timer.stop("vits_wn_layer_fwd", e0, (2.0 * b * t * H * (2 * H * k + c_rs),
+                                                   es * (b * t * H * (2 + (0 if last else 1) + (1 if accumulate else 0) + (2 if pre is not None else 0)
+                                                                      + (1 if acts is not None else 0)) + (2 * k + c_rs // H) * H * H)),
+                        shape=f"b{b} t{t} H{H} k{k} d{dil} last{int(bool(last))} {str(x.dtype)[6:]}")
+    if rc == _lib.E_UNSUPPORTED:
+        return NotImplemented
+    _lib.check(rc, "vits_wn_layer_fwd")
+    return h_out
+
+
+def wn_layer_bwd(d_h, d_o, pre, w_rs_t, w_in_t, lengths, dil, last, d_pre, d_h_out):
+    """Data-gradient half of one WaveNet layer's backward in one launch (csrc/wn_layer.hip, vits_wn_layer_bwd):
+    d_pre = gate'(pre) * ([d_h | d_o] . W_rs) (masked) into `d_pre` [b,t,2H]; d_h_out = (d_h + conv^T(d_pre; W_in)) * mask.
+    d_h / d_o / d_h_out [b,t,H] may be column slices of wider tensors; w_rs_t [1][H][2H|H], w_in_t [k][H][2H] are the arena's
+    data-gradient operands.  Returns False when the kernel does not take the shape."""
+    _lib.require_cuda(d_o, pre, w_rs_t, w_in_t, d_pre, d_h_out)
+    b, t, H = d_o.shape
+    k = w_in_t.size(0)
+    if H % 16 != 0 or H > 192 or k % 2 == 0:
+        return False
+    dt = d_o.dtype
+    assert all(x.dtype == dt for x in (pre, w_rs_t, w_in_t, d_pre, d_h_out)) and (d_h is None or d_h.dtype == dt)
+    assert w_rs_t.is_contiguous() and w_in_t.is_contiguous()
+    assert tuple(w_in_t.shape) == (k, H, 2 * H) and tuple(w_rs_t.shape) == (1, H, H if last else 2 * H), (tuple(w_in_t.shape), tuple(w_rs_t.shape))
+    assert tuple(pre.shape) == (b, t, 2 * H) and tuple(d_pre.shape) == (b, t, 2 * H) and tuple(d_h_out.shape) == (b, t, H)
+    assert last or tuple(d_h.shape) == (b, t, H)
+    assert lengths is None or lengths.dtype == torch.int32
+    p = lambda v: None if v is None else v.data_ptr()
+    d = _lib.WnLayerBwdDesc(dtype=_DT[dt], b=b, t=t, h=H, k=k, dil=dil, last=int(bool(last)),
+                            ld_dh=0 if d_h is None else _rows(d_h, "d_h"), ld_do=_rows(d_o, "d_o"), ldpre=_rows(pre, "pre"),
+                            lddpre=_rows(d_pre, "d_pre"), ldout=_rows(d_h_out, "d_h_out"),
+                            d_h=None if last else p(d_h), d_o=d_o.data_ptr(), pre=pre.data_ptr(), w_rs_t=w_rs_t.data_ptr(),
+                            w_in_t=w_in_t.data_ptr(), d_pre=d_pre.data_ptr(), d_h_out=d_h_out.data_ptr(), lengths=p(lengths))
+    import ctypes
+    e0 = _lib.timer.start("vits_wn_layer_bwd")
+    rc = _lib.lib().vits_wn_layer_bwd(ctypes.addressof(d), _lib.stream_ptr())
+    if e0 is not None:
+        es = d_o.element_size()
+        c_rs = H if last else 2 * H
+        _lib.timer.stop("vits_wn_layer_bwd", e0, (2.0 * b * t * H * (2 * H * k + c_rs),
+                                                   es * (b * t * H * (6 + (0 if last else 1)) + (2 * k + c_rs // H) * H * H)),
+                        shape=f"b{b} t{t} H{H} k{k} d{dil} last{int(bool(last))} {str(dt)[6:]}")
+    if rc == _lib.E_UNSUPPORTED:
+        return False
+    _lib.check(rc, "vits_wn_layer_bwd")
+    return True
+
+
 def colsum(x, per_item=False):
     """float32 column sums of a contiguous channels-last [b, t, c] tensor: per item ([b, c]) or over the batch ([c])."""
     _lib.require_cuda(x)
@@ -424,6 +503,7 @@ def workspace(nbytes, device):
 
 
 _side_streams = {}
+_open_branches = []          # SideBranch objects between __enter__ and __exit__ (innermost last)
 
 
 class SideBranch:
@@ -451,6 +531,15 @@ class SideBranch:
         self._ctx = None
 
     def __enter__(self):
+        # A branch opened inside another one (from its side stream, or twice on one lane) is refused: the nested fork/join
+        # pattern is what crashed hipStreamEndCapture when the step was captured — an inner branch joins into
+        # the OUTER side stream, so the capture's origin stream never sees that lane rejoin.  Open branches one after the
+        # other from the main stream instead (they still overlap each other on different lanes).
+        if _open_branches:
+            raise RuntimeError("SideBranch: opened inside another open branch (nested branches are not supported)")
+        if any(self.main.cuda_stream == s.cuda_stream for s in _side_streams.values()):
+            raise RuntimeError("SideBranch: opened from a side stream (nested branches are not supported)")
+        _open_branches.append(self)
         self.side.wait_stream(self.main)
         for t in self.inputs:
             t.record_stream(self.side)
@@ -460,6 +549,8 @@ class SideBranch:
 
     def __exit__(self, *exc):
         self._ctx.__exit__(*exc)
+        if _open_branches and _open_branches[-1] is self:
+            _open_branches.pop()
         return False
 
     def join(self, *outputs):

@@ -87,13 +87,14 @@ def _basis(sampling_rate, n_fft, num_mels, fmin, fmax, dtype, device):
     return mel_basis[key]
 
 
-def spectrogram_torch(y, n_fft, sampling_rate, hop_size, win_size, center=False):
+def spectrogram_torch(y, n_fft, sampling_rate, hop_size, win_size, center=False, prepadded=False):
     """y [b, t] in [-1, 1] -> linear magnitude [b, n_fft/2+1, frames]; reflect pad (n_fft-hop)/2,
     periodic Hann, sqrt(re^2 + im^2 + 1e-6) (reference mel_processing.py:51-70).  The reference's
-    range check prints (two host syncs per call, :52-55) are dropped."""
+    range check prints (two host syncs per call, :52-55) are dropped.  prepadded: `y` already carries the padding
+    (data_utils.spectrograms_on_device pads every item of a batch at its own ends)."""
     if center:
         raise NotImplementedError("the reference always calls with center=False")
-    return kernels.stft_magnitude(y, n_fft, hop_size, win_size, _window(win_size, y.dtype, y.device))
+    return kernels.stft_magnitude(y, n_fft, hop_size, win_size, _window(win_size, y.dtype, y.device), prepadded=prepadded)
 
 
 def spec_to_mel_torch(spec, n_fft, num_mels, sampling_rate, fmin, fmax):

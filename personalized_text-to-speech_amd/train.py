@@ -308,10 +308,11 @@ def evaluate(hps, generator, batch, max_len=1000):
             "gt/audio": y[0, :, :int(y_lengths[0])], "attn": attn[0, 0]}
 
 
-def synthetic_batch(hps, batch_size, t_y_range, device, seed=1234, rank=0, spec_fn=None):
+def synthetic_batch(hps, batch_size, t_y_range, device, seed=1234, rank=0, spec_fn=None, frames_per_token=5):
     """Deterministic synthetic minibatch of SURVEY.md §8(d): lengths linspace(lo, hi) sorted
     descending (TextAudioSpeakerCollate, data_utils.py:129-131), text ids with interspersed blanks
-    (commons.py:24-27, T_x = 2n+1), waveforms = 3 sinusoids + noise peak-normalised to 0.5,
+    (commons.py:24-27, T_x = 2n+1, n = T_y / frames_per_token: 5 gives C2's T_x <= 201 at 500 frames, 8 gives C1's
+    T_x = (101, 81) at (400, 320) frames), waveforms = 3 sinusoids + noise peak-normalised to 0.5,
     spec = spectrogram_torch(wav), speaker ids round-robin."""
     if spec_fn is None:
         from .mel_processing import spectrogram_torch
@@ -320,7 +321,7 @@ def synthetic_batch(hps, batch_size, t_y_range, device, seed=1234, rank=0, spec_
     lo, hi = t_y_range
     hop = hps.data.hop_length
     t_y = torch.linspace(lo, hi, batch_size).round().long().flip(0)
-    n_tok = torch.round(t_y / 5).long()
+    n_tok = torch.round(t_y / frames_per_token).long()
     t_x = 2 * n_tok + 1
     B, T_x, T_y = batch_size, int(t_x.max()), int(t_y.max())
     x = torch.zeros(B, T_x, dtype=torch.long)

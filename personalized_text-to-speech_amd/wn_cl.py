@@ -166,6 +166,9 @@ def wn_cond(wn, g, n_items):
     return c.view(n_items, wn.n_layers, 2 * wn.hidden_channels).transpose(0, 1).contiguous()
 
 
+FUSED_LAYERS = True          # one launch per WaveNet layer and direction (csrc/wn_layer.hip); False = the three-launch composition
+
+
 class WNFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, plan, dtype, x, lengths, cond, *wb):
@@ -179,22 +182,31 @@ class WNFn(torch.autograd.Function):
         cd = None if cond is None else cond.detach().float().contiguous()
         out = torch.empty_like(h)
         saved = []
+        fused = FUSED_LAYERS and lengths is not None
         for i in range(L):
             r_in, b_in, r_rs, b_rs = R[4 * i], bias[4 * i + 1], R[4 * i + 2], bias[4 * i + 3]
             d = plan.dils[i]
             pre = torch.empty(h.size(0), h.size(1), 2 * H, device=h.device, dtype=dtype)
-            acts = C(h, r_in.fwd, b_in, bias_b=None if cd is None else cd[i], dil=d, pad=(k * d - d) // 2,
-                     flags=K.CONV_GATE, gate_h=H, out2=pre)
-            acc = K.CONV_ACCUM if i > 0 else 0
-            if i < L - 1:                                   # rows [0, H) of the res_skip operand feed the residual, [H, 2H) the skip sum
-                h_next = C(acts, r_rs.fwd[:, :H], b_rs[:H], res=h, lengths=lengths, flags=K.CONV_MASK_OUT)
-                C(acts, r_rs.fwd[:, H:], b_rs[H:], out=out, lengths=lengths, flags=K.CONV_MASK_OUT | acc)
-            else:
-                h_next = None
-                C(acts, r_rs.fwd, b_rs, out=out, lengths=lengths, flags=K.CONV_MASK_OUT | acc)
+            h_next = NotImplemented
+            if fused:                                       # the whole layer as one launch (csrc/wn_layer.hip)
+                acts = torch.empty_like(h)
+                h_next = K.wn_layer_fwd(h, r_in.fwd, b_in, None if cd is None else cd[i], r_rs.fwd, b_rs, lengths, d, out,
+                                        accumulate=i > 0, last=i == L - 1, pre=pre, acts=acts)
+                fused = h_next is not NotImplemented
+            if h_next is NotImplemented:
+                acts = C(h, r_in.fwd, b_in, bias_b=None if cd is None else cd[i], dil=d, pad=(k * d - d) // 2,
+                         flags=K.CONV_GATE, gate_h=H, out2=pre)
+                acc = K.CONV_ACCUM if i > 0 else 0
+                if i < L - 1:                               # rows [0, H) of the res_skip operand feed the residual, [H, 2H) the skip sum
+                    h_next = C(acts, r_rs.fwd[:, :H], b_rs[:H], res=h, lengths=lengths, flags=K.CONV_MASK_OUT)
+                    C(acts, r_rs.fwd[:, H:], b_rs[H:], out=out, lengths=lengths, flags=K.CONV_MASK_OUT | acc)
+                else:
+                    h_next = None
+                    C(acts, r_rs.fwd, b_rs, out=out, lengths=lengths, flags=K.CONV_MASK_OUT | acc)
             saved += [h, pre, acts]
             h = h_next
         ctx.plan, ctx.dtype, ctx.lengths, ctx.has_cond, ctx.R = plan, dtype, lengths, cd is not None, R
+        ctx.fused = fused
         ctx.save_for_backward(*saved)
         return out
 
@@ -216,6 +228,8 @@ class WNFn(torch.autograd.Function):
         d_h, d_o = dcat[..., :H], dcat[..., H:]
         dcond = [] if ctx.has_cond else None
         defer = K.DeferredReductions(d_out.device)      # the 2L slab reductions of this stack run as one launch at the end
+        if ctx.fused:
+            return WNFn._backward_fused(ctx, dcat, saved, grads, defer)
         for i in reversed(range(L)):
             acts, pre, h = saved.pop(), saved.pop(), saved.pop()
             r_in, r_rs = R[4 * i], R[4 * i + 2]
@@ -237,6 +251,44 @@ class WNFn(torch.autograd.Function):
         defer.flush()
         dc = torch.stack(dcond[::-1], 0) if dcond is not None else None
         return (None, None, d_h.contiguous(), None, dc, *grads)
+
+    @staticmethod
+    def _backward_fused(ctx, dcat, saved, grads, defer):
+        """One data-gradient launch per layer (vits_wn_layer_bwd: the 1x1 data gradient, the gate's chain rule and the k-tap data
+        gradient with its residual path) between two [d_h | d_o] buffers, both holding d_o in their right halves: a layer
+        reads one and writes its d_h into the other's left half, so neighbouring time tiles never see a half-updated row.
+        The weight gradients follow each layer's launch (stream order protects the buffer they read); the gradient of the
+        conditioning is ONE per-item column sum over all layers' d_pre at the end."""
+        plan, lengths, R = ctx.plan, ctx.lengths, ctx.R
+        WG = K.conv1d_cl_wgrad_raw
+        H, L, k = plan.H, plan.L, plan.k
+        b, t = dcat.size(0), dcat.size(1)
+        dev, dtype = dcat.device, dcat.dtype
+        bufs = [dcat, torch.empty_like(dcat)]
+        bufs[1][..., H:].copy_(dcat[..., H:])
+        d_pre_all = torch.empty(L, b, t, 2 * H, device=dev, dtype=dtype)
+        cur = 0
+        for i in reversed(range(L)):
+            acts, pre, h = saved.pop(), saved.pop(), saved.pop()
+            r_in, r_rs = R[4 * i], R[4 * i + 2]
+            d = plan.dils[i]
+            pad = (k * d - d) // 2
+            last = i == L - 1
+            src, dst = bufs[cur], bufs[1 - cur]
+            ok = K.wn_layer_bwd(None if last else src[..., :H], src[..., H:], pre, WA.bwd_operand(r_rs), WA.bwd_operand(r_in), lengths, d, last,
+                                d_pre_all[i], dst[..., :H])
+            if not ok:
+                raise RuntimeError("vits_wn_layer_bwd refused a shape vits_wn_layer_fwd accepted")
+            db_rs = torch.empty(H if last else 2 * H, dtype=torch.float32, device=dev)
+            grads[4 * i + 2] = WG(acts, src[..., H:] if last else src, 1, out=r_rs.claim_dw(ctx), dbias=db_rs, defer=defer)
+            grads[4 * i + 3] = db_rs
+            db_in = torch.empty(2 * H, dtype=torch.float32, device=dev)
+            grads[4 * i] = WG(h, d_pre_all[i], k, dil=d, pad=pad, out=r_in.claim_dw(ctx), dbias=db_in, defer=defer)
+            grads[4 * i + 1] = db_in
+            cur = 1 - cur
+        defer.flush()
+        dc = K.colsum(d_pre_all.view(L * b, t, 2 * H), per_item=True).view(L, b, 2 * H) if ctx.has_cond else None
+        return (None, None, bufs[cur][..., :H].contiguous(), None, dc, *grads)
 
 
 def wn_forward_cl(wn, x_cl, lengths, g):

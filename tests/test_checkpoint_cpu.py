@@ -48,3 +48,40 @@ def test_reference_layout_file_with_missing_keys(pkg, tmp_path):
     pkg.utils.load_checkpoint(path, fresh, None)
     assert torch.equal(fresh.state_dict()["dp.pre.weight"], keep) and torch.equal(fresh.state_dict()["enc_q.pre.weight"], sd["enc_q.pre.weight"])
     assert all(k.startswith("dp.") for k in pkg.utils.load_checkpoint.last_missing) and pkg.utils.load_checkpoint.last_missing
+
+
+def test_file_written_by_the_reference_loads(pkg, golden_dir):
+    """tests/golden/ref_G_tiny.pth was written by the reference's own utils.save_checkpoint (tools/gen_golden_misc.py: its tiny
+    SynthesizerTrn after one torch.optim.AdamW step).  It loads through the weights-only loader into the product modules and
+    into FlatAdamW-compatible optimizer state; the same script checked the reverse direction (a file written here read by the
+    reference's load_checkpoint) when it generated the fixture."""
+    import os
+    import numpy as np
+    g, cfg = load_tiny()
+    m = np.load(os.path.join(golden_dir, "misc.npz"))
+    assert int(m["ckpt/reverse_ok"]) == 1
+    net = pkg.SynthesizerTrn(cfg["n_vocab"], cfg["spec_channels"], cfg["segment_size"], n_speakers=cfg["n_speakers"], **cfg["model"])
+    opt = torch.optim.AdamW(net.parameters(), 1e-3, betas=(0.8, 0.99), eps=1e-9)
+    _, _, lr, it = pkg.utils.load_checkpoint(os.path.join(golden_dir, "ref_G_tiny.pth"), net, opt)
+    assert it == int(m["ckpt/iteration"]) and lr == float(m["ckpt/learning_rate"])
+    assert not pkg.utils.load_checkpoint.last_missing
+    sd = net.state_dict()
+    for k in m.files:
+        if k.startswith("ckpt/sd/"):
+            assert torch.equal(sd[k[8:]], torch.from_numpy(m[k])), k
+    st = opt.state_dict()["state"]
+    assert len(st) == int(m["ckpt/opt_n_state"]) and float(st[int(m["ckpt/opt_first_id"])]["step"]) == float(m["ckpt/opt_step"])
+    assert torch.equal(st[int(m["ckpt/opt_first_id"])]["exp_avg"], torch.from_numpy(m["ckpt/opt_first_exp_avg"]))
+
+
+def test_larger_saved_speaker_table_keeps_the_models_own(pkg, golden_dir):
+    """A many-speaker checkpoint into a model with FEWER speakers (and no drop_speaker_emb): the reference's row assignment
+    raises inside its bare try/except and the model keeps its own table (utils.py:162-177)."""
+    import os
+    g, cfg = load_tiny()
+    small = pkg.SynthesizerTrn(cfg["n_vocab"], cfg["spec_channels"], cfg["segment_size"], n_speakers=cfg["n_speakers"] - 1, **cfg["model"])
+    own = small.emb_g.weight.detach().clone()
+    pkg.utils.load_checkpoint(os.path.join(golden_dir, "ref_G_tiny.pth"), small, None)
+    assert torch.equal(small.emb_g.weight, own) and pkg.utils.load_checkpoint.last_missing == ["emb_g.weight"]
+    ref = build_tiny(pkg, g, cfg)
+    assert not torch.equal(small.enc_q.pre.weight, ref.enc_q.pre.weight)      # (the file holds the post-step weights, not the npz's)

@@ -279,3 +279,99 @@ def test_mpd_generator_step_half_batch(pkg):
     ro, go, fro, fgo = O.mpd(sd, y, yb)
     (O.generator_loss(go) + O.feature_loss(fro, fgo)).backward()
     assert rel_err(ya.grad, yb.grad) < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Fixtures of tools/gen_golden_misc.py (tests/golden/misc.npz + ref_G_tiny.pth, produced by running the reference)
+def _misc():
+    import os
+    from conftest import ROOT
+    return np.load(os.path.join(ROOT, "tests", "golden", "misc.npz")), os.path.join(ROOT, "tests", "golden", "ref_G_tiny.pth")
+
+
+def test_evaluate_matches_reference(pkg):
+    """train.evaluate (finetune_speaker_v2.py:313-368) on the checkpoint the reference wrote: the generated waveform cut to
+    y_hat_lengths and the alignment equal what the reference's evaluate() computes before its plotting calls; the mels are the
+    product's mel of those waveforms (the mel filter bank itself is parity-unpinned)."""
+    from importlib import import_module
+    tr = import_module("personalized_text-to-speech_amd.train")
+    cfgs = import_module("personalized_text-to-speech_amd.configs")
+    mel = import_module("personalized_text-to-speech_amd.mel_processing")
+    m, ckpt = _misc()
+    g, cfg = load_tiny()
+    net = pkg.SynthesizerTrn(cfg["n_vocab"], cfg["spec_channels"], cfg["segment_size"], n_speakers=cfg["n_speakers"], **cfg["model"])
+    pkg.utils.load_checkpoint(ckpt, net, None)
+    net = net.to("cuda:0").train()
+    hps = cfgs.HParams({"data": {"hop_length": 16, "filter_length": 32, "win_length": 32, "n_mel_channels": 8, "sampling_rate": 22050,
+                                 "mel_fmin": 0.0, "mel_fmax": None}})
+    x, x_len, spec, spec_len, sid = inputs(g, "cuda:0")
+    torch.manual_seed(0)
+    y = torch.rand(2, 1, 24 * 16, device="cuda:0") - 0.5
+    y_len = spec_len * 16
+    noise = [torch.from_numpy(m[f"eval/noise{i}"]) for i in range(int(m["eval/n_noise"]))]
+    with pkg.rng.noise.replay(noise):
+        out = tr.evaluate(hps, net, (x, x_len, spec, spec_len, y, y_len, sid))
+    assert net.training                                           # back in train mode, like the reference
+    assert out["gen/audio"].shape == tuple(m["eval/gen_audio"].shape)
+    assert rel_err(out["gen/audio"], m["eval/gen_audio"]) < TOL
+    assert np.array_equal(out["attn"].cpu().numpy(), m["eval/attn"])
+    assert torch.equal(out["gt/audio"], y[0, :, :int(y_len[0])])
+    want = mel.mel_spectrogram_torch(torch.from_numpy(m["eval/gen_audio"]).to("cuda:0").float(), 32, 8, 22050, 16, 32, 0.0, None)[0]
+    n = want.size(1)
+    assert rel_err(out["gen/mel"][:, :n], want) < TOL
+    assert rel_err(out["gt/mel"], mel.spec_to_mel_torch(spec[:1].float(), 32, 8, 22050, 0.0, None)[0]) < 1e-6
+
+
+def test_spectrograms_on_device_match_per_file_reference(pkg):
+    """data_utils.spectrograms_on_device (GPU branch: the DFT product on the convolution kernel) on a zero-padded batch of items
+    of different lengths == the reference's spectrogram_torch per FILE (tests/golden/misc.npz loader/*), frame mask included."""
+    import types
+    from importlib import import_module
+    D = import_module("personalized_text-to-speech_amd.data_utils")
+    m, _ = _misc()
+    nfft, hop = m["loader/hp"].tolist()
+    wav, wav_len, spec, spec_len = (torch.from_numpy(m["loader/collate/" + k]).to("cuda:0") for k in ("wav", "wav_len", "spec", "spec_len"))
+    hps = types.SimpleNamespace(data=types.SimpleNamespace(filter_length=nfft, hop_length=hop, win_length=nfft, sampling_rate=22050))
+    got, got_len = D.spectrograms_on_device(wav, wav_len, hps)
+    assert torch.equal(got_len, spec_len)
+    t = spec.size(2)
+    assert rel_err(got[:, :, :t], spec) < 1e-4
+    for i, n in enumerate(spec_len.tolist()):                      # zero beyond each item's own frame count
+        assert float(got[i, :, n:].abs().max()) == 0.0 if n < got.size(2) else True
+
+
+def test_duration_predictor_matches_reference(pkg):
+    """models.DurationPredictor (reference models.py:98-132, the use_sdp=False branch) on the convolution / LayerNorm kernels:
+    output and every parameter gradient against the reference's own module (fp32)."""
+    from importlib import import_module
+    M = import_module("personalized_text-to-speech_amd.models")
+    m, _ = _misc()
+    cin, cf, k, gin = m["durpred/cfg"].tolist()
+    dp = M.DurationPredictor(cin, cf, k, 0.0, gin_channels=gin)
+    dp.load_state_dict({n[11:]: torch.from_numpy(m[n]) for n in m.files if n.startswith("durpred/sd/")})
+    dp = dp.to("cuda:0").train()
+    t = lambda n: torch.from_numpy(m["durpred/" + n]).to("cuda:0")
+    y = dp(t("x"), t("x_mask"), g=t("g"))
+    assert y.shape == tuple(m["durpred/y"].shape) and rel_err(y, m["durpred/y"]) < TOL
+    (y * t("w")).sum().backward()
+    for n, p in dp.named_parameters():
+        assert p.grad is not None, n
+        assert rel_err(p.grad, m["durpred/grad/" + n]) < TOL, n
+
+
+def test_side_branch_refuses_nesting(pkg):
+    """kernels.SideBranch: a branch opened inside another open branch (or from a side stream) raises instead of building the
+    fork/join pattern that crashed hipStreamEndCapture; sequential branches on different lanes stay allowed."""
+    K = pkg.kernels
+    x = torch.ones(4, device="cuda:0")
+    a = K.SideBranch(x.device, x, lane=0)
+    with a:
+        y = x * 2
+        with pytest.raises(RuntimeError, match="nested"):
+            K.SideBranch(x.device, x, lane=1).__enter__()
+    b = K.SideBranch(x.device, x, lane=1)
+    with b:
+        z = x * 3
+    y, z = a.join(y), b.join(z)
+    torch.cuda.synchronize()
+    assert float((y + z).sum()) == 20.0

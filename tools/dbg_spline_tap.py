@@ -18,12 +18,18 @@ orig_mask = K.lrelu_mask_bwd
 
 
 def tapped_bwd(ctx, dout, dlogdet):
+    if not active[0]:
+        return orig_bwd(ctx, dout, dlogdet)
+    xd, hd, md = ctx.saved_tensors
+    pre = {"x2": xd.clone(), "h": hd.clone(), "mask": md.clone(), "dy2": dout.float().clone(), "dlogdet": dlogdet.float().clone()}
     res = orig_bwd(ctx, dout, dlogdet)
-    if active[0]:
-        xd, hd, md = ctx.saved_tensors
-        rec = {"x2": xd.clone(), "h": hd.clone(), "mask": md.clone(), "dy2": dout.float().clone(), "dlogdet": dlogdet.float().clone(),
-               "dx2": res[0].clone(), "gh": res[1].clone()}
-        taps.append(rec)
+    rec = {"dx2": res[0].clone(), "gh": res[1].clone()}
+    res_b = orig_bwd(ctx, dout, dlogdet)                       # the same launch again, right behind the first, into other buffers
+    rec.update({"dx2_again": res_b[0].clone(), "gh_again": res_b[1].clone()})
+    rec.update({k + "_before": v for k, v in pre.items()})
+    rec.update({"x2_after": xd.clone(), "h_after": hd.clone(), "mask_after": md.clone(), "dy2_after": dout.float().clone(),
+                "dlogdet_after": dlogdet.float().clone()})
+    taps.append(rec)
     return res
 
 
@@ -67,19 +73,32 @@ def run():
     return [{k: v.detach().cpu().clone() for k, v in rec.items()} for rec in taps], ft.optim_g.flat_p.detach().cpu().clone()
 
 
+def within(cur, tag):
+    for ci, rec in enumerate(cur):
+        if "gh_again" not in rec:
+            continue
+        for a, b in (("gh", "gh_again"), ("dx2", "dx2_again")) + tuple((k + "_before", k + "_after") for k in ("x2", "h", "mask", "dy2", "dlogdet")):
+            if not torch.equal(rec[a], rec[b]):
+                n = int((rec[a].float() != rec[b].float()).sum())
+                print(f"   WITHIN {tag} call {ci}: {a} != {b} in {n} elements", flush=True)
+
+
 NR = int(os.environ.get("NREP", "30"))
 base, p0 = run()
+within(base, "replay 1")
 n_bad = 0
 for r in range(1, NR):
     cur, p1 = run()
+    within(cur, f"replay {r + 1}")
     lines = []
     for ci, (a, b) in enumerate(zip(base, cur)):
         for k in a:
             if not torch.equal(a[k], b[k]):
                 A, B = a[k].float(), b[k].float()
                 idx = (A != B).nonzero()
-                lines.append(f"   call {ci} {k} shape {tuple(A.shape)}: {idx.size(0)} elements differ; first {idx[:6].tolist()}")
-                for ix in idx[:4].tolist():
+                rows = sorted({tuple(i[:-1]) for i in idx.tolist()})
+                lines.append(f"   call {ci} {k} shape {tuple(A.shape)}: {idx.size(0)} elements differ; first {idx[:6].tolist()}; rows {rows[0]}..{rows[-1]} ({len(rows)} rows)")
+                for ix in idx[:2].tolist():
                     row = ix[0]
                     lines.append(f"      at {ix}: base {A[tuple(ix)].item():.6e}  now {B[tuple(ix)].item():.6e}")
                     if A.dim() == 2:
