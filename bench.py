@@ -170,6 +170,8 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the fp32 (parity mode) timing reported next to the bf16 headline")
     ap.add_argument("--segmented", action="store_true", help="force the three-graph (data-parallel) form of the captured step at N = 1")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying the captured hipGraph")
+    ap.add_argument("--exchange", action="store_true", help="N = 1 only: run the data-parallel gradient exchange anyway (one-rank RCCL group, "
+                    "three graphs with bucket all-reduces between them) to time what that form costs on one GPU")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -188,6 +190,9 @@ def main():
         else:
             dist.init_process_group(os.environ["VITS_DIST_BACKEND"], rank=rank, world_size=world)
 
+    if world == 1 and args.exchange:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
     coll_device = device if (world == 1 or dist.get_backend() == "nccl") else torch.device("cpu")   # small control collectives
 
     from importlib import import_module
@@ -203,7 +208,7 @@ def main():
         return
     cfg_name, batch_size, t_y_range = cfgs.WORKLOADS[args.workload]
     hps = cfgs.get(cfg_name)
-    tuner = tr.FineTuner(hps, device, amp=not args.fp32)
+    tuner = tr.FineTuner(hps, device, amp=not args.fp32, force_exchange=world == 1 and args.exchange)
     if args.branches is not None:
         tuner.side_branches = frozenset(b for b in args.branches.split(",") if b)
     batch = tr.synthetic_batch(hps, batch_size, t_y_range, device, rank=rank)
@@ -216,7 +221,7 @@ def main():
     use_graph = not args.eager
     branch_note = None
     if use_graph and world == 1:
-        cap = tuner.capture_segments if args.segmented else tuner.capture
+        cap = tuner.capture_segments if (args.segmented or args.exchange) else tuner.capture
         cap(batch, warmup=3)
         try:
             for _ in range(4):                           # same state -> same result, and agrees with the eager step: four rounds,
@@ -293,6 +298,12 @@ def main():
         tuner.step(batch)
     torch.cuda.synchronize()
     P._lib.timer.enabled = False
+    # what a caller without a stable shape gets: the same step launched from Python, no graph (3 steps, untimed for the headline)
+    t1 = time.perf_counter()
+    for _ in range(3):
+        tuner.step(batch)
+    torch.cuda.synchronize()
+    eager_ms = (time.perf_counter() - t1) / 3 * 1e3
     if world > 1:
         t = torch.tensor([elapsed], device=coll_device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -332,20 +343,25 @@ def main():
         line = dict(metric="22.05 kHz waveform samples/sec, VITS fine-tune fwd+bwd", value=samples / elapsed, unit="samples/s",
                     n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3,
                     higher_is_better=True, scaling="weak", vs_baseline=None, dtype="fp32" if args.fp32 else "bf16",
-                    data="synthetic",
+                    data="synthetic", eager_ms_per_step=eager_ms,
                     config=dict(workload=f"{args.workload}: {cfg_name}.json, per-rank batch {batch_size}, T_y<= {T_y} frames, "
                                          f"T_x<= {T_x} tokens, segment {hps.train.segment_size} samples, fwd+bwd+AdamW (G and D)",
-                                parallelism=f"dp{world}", execution=("hipGraph replay" if world == 1 and not args.segmented else "three hipGraphs, gradient all-reduce between them") if use_graph else "eager launches",
+                                parallelism=f"dp{world}", execution=("hipGraph replay" if world == 1 and not (args.segmented or args.exchange) else "three hipGraphs, gradient all-reduce between them") if use_graph else "eager launches",
                                 side_stream_branches=sorted(tuner.side_branches), kernels=P.kernels.BACKENDS, losses=losses),
                     roofline=roof)
         if branch_note:
             line["config"]["note"] = branch_note
         if world == 1 and not args.fp32 and not args.no_secondary:
             line["secondary"] = secondary_fp32(tr, hps, device, batch, batch_size)
+            # BASELINE.json configs[3] (C4, inference) beside the headline: the same numbers `--workload C4` prints on its own
+            c4 = argparse.Namespace(**{**vars(args), "steps": 5, "warmup": 2})
+            r = bench_infer(c4, P, cfgs, device)
+            line["secondary"]["c4_infer"] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config")}
+            line["secondary"]["c4_infer"]["roofline_frac"] = r["roofline"]["frac"]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfgs)
         print(json.dumps(line))
-    if world > 1:
+    if world > 1 or (dist.is_available() and dist.is_initialized()):
         dist.destroy_process_group()
 
 

@@ -177,6 +177,18 @@ typedef struct vits_wgrad_pending {
 int vits_conv1d_cl_wgrad_deferred(const vits_wgrad_desc* desc, void* stream, vits_wgrad_pending* pending);
 int vits_wgrad_reduce_pending(const vits_wgrad_pending* list, int count, void* stream);
 
+/* The weight (+ bias) gradients of a GROUP of stride-1 "same" convolutions (t_out == t, groups == 1) in one launch per
+ * taps-per-group class (csrc/conv1d_wgrad_batch.hip): the layers of a stack are each other's parallelism, so with enough 64 x 64
+ * tiles in the group every workgroup walks its whole (b, t) reduction and nothing but dw is written (no per-split slabs).
+ * descs[i] are ordinary vits_wgrad_desc (same dtype); `workspace` is only used when the group is too small to fill the chip:
+ * then the reduction is split vits_conv1d_cl_wgrad_batch_splits(descs, count) ways — give every entry a workspace of at least
+ * splits * (k*c_out*c_in + c_out) floats and a `pending` array of `count` entries (pending[i].splits == 0: entry i is final),
+ * and run vits_wgrad_reduce_pending on it afterwards; without workspace / pending the entries run unsplit.
+ * Returns VITS_E_UNSUPPORTED if any entry is not eligible (strided, grouped, dilated beyond the staged halo ...): the caller
+ * then issues the per-layer calls. */
+int vits_conv1d_cl_wgrad_batch_splits(const vits_wgrad_desc* descs, int count);
+int vits_conv1d_cl_wgrad_batch(const vits_wgrad_desc* descs, int count, void* stream, vits_wgrad_pending* pending);
+
 /* ------------------------------------------------------------------------------------------
  * One WaveNet layer per launch (csrc/wn_layer.hip).
  *
@@ -185,17 +197,32 @@ int vits_wgrad_reduce_pending(const vits_wgrad_pending* list, int count, void* s
  *     x_in = in_layers[i](x);  acts = tanh((x_in + g_l)[:, :H]) * sigmoid((x_in + g_l)[:, H:]);
  *     res_skip = res_skip_layers[i](acts);  x = (x + res_skip[:, :H]) * x_mask;  output += res_skip[:, H:]
  *   (last layer: res_skip has H rows, all of them skip).  Channels-last [b][t][c]; rows t >= lengths[b] of x must be zero.
- *   forward : x [b][t][H];  w_in [k][2H][H], w_rs [1][2H | H][H] (dtype of x; the weight arena's forward operands), b_in / b_rs
+ *   forward : x [b][t][H];  w_in [k][2H][H], w_rs [1][2H | H][H] (dtype of x; the weight arena's forward operands, PACKED), b_in / b_rs
  *             float32, cond float32 [b][2H] (this layer's slice of cond_layer(g)) or NULL;
  *             pre [b][t][2H] (pre-activations incl. bias and cond; optional) and acts [b][t][H] (optional) are the backward's
  *             saved tensors;  h_out [b][t][H] = (x + res) * mask (NULL for the last layer);  skip [b][t][H] (+)= skip * mask.
  *   backward: dcat [b][t][2H] = [d_h | d_o] (d_o = the masked gradient of the stack's output, the same for every layer; the last
  *             layer passes d_o alone, lddcat = its row pitch);  w_rs_t [1][H][2H | H] and w_in_t [k][H][2H] (tap-reversed) are the
- *             arena's data-gradient operands;  d_pre [b][t][2H] = gate'(pre) * (dcat . W_rs), masked — written for the weight
+ *             arena's data-gradient operands, PACKED;  d_pre [b][t][2H] = gate'(pre) * (dcat . W_rs), masked — written for the weight
  *             gradients;  d_h_out [b][t][H] = d_h + conv^T(d_pre; W_in), masked (last layer: no d_h term).
  *   dtype VITS_DT_BF16 or VITS_DT_F32 (exact fp32 products); H % 16 == 0, H <= 192, k odd.
  *   Returns VITS_E_UNSUPPORTED for other shapes (the caller then composes the layer from vits_conv1d_cl launches).
  * ------------------------------------------------------------------------------------------ */
+/* Operand packing for the two calls below: w_in / w_rs (forward) and w_rs_t / w_in_t (backward) are NOT the arena's row-major
+ * operands but their re-ordering by vits_wn_pack into MFMA-fragment order ([column tile][reduction step][lane][16 bytes]), so that
+ * every weight load of a wave reads 1 KiB of consecutive memory.  One vits_wn_pack launch packs all operands of a stack:
+ *   mode 0: w_in  [taps][2H][H]      -> 32-column tiles, gate-interleaved (16 tanh rows | their 16 sigmoid rows), 32-byte steps
+ *   mode 1: w_rs  [1][2H | H][H]     -> 32-column tiles in natural order, 32-byte steps
+ *   mode 2: w_rs_t [1][H][2H | H], w_in_t [taps][H][2H] (the data-gradient operands) -> 16-row tiles, 64-byte steps (tails zero)
+ * src: taps x rows x rowbytes bytes, row-major; dst: vits_wn_pack_bytes(...) bytes; spt = steps per tap (rowbytes / 32 for modes
+ * 0 and 1, ceil(rowbytes / 64) for mode 2). */
+typedef struct vits_wn_pack_seg {
+  const void* src;  void* dst;
+  int32_t mode, h, rows, rowbytes, taps, spt;
+} vits_wn_pack_seg;
+size_t vits_wn_pack_bytes(int mode, int dtype, int h, int rows, int k_elems, int taps);
+int vits_wn_pack(const vits_wn_pack_seg* segs, int count, void* stream);
+
 typedef struct vits_wn_layer_desc {
   int32_t dtype, b, t, h, k, dil;
   int32_t last;             /* the stack's last layer: res_skip has H rows (skip only)                         */

@@ -48,9 +48,13 @@ SIGNATURES = {
     "vits_conv1d_cl_wgrad": (c_int, [c_void_p, c_void_p]),
     "vits_conv1d_cl_wgrad_deferred": (c_int, [c_void_p, c_void_p, c_void_p]),
     "vits_wgrad_reduce_pending": (c_int, [c_void_p, c_int, c_void_p]),
+    "vits_conv1d_cl_wgrad_batch_splits": (c_int, [c_void_p, c_int]),
+    "vits_conv1d_cl_wgrad_batch": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "vits_conv1d_cl": (c_int, [c_void_p, c_void_p]),
     "vits_wn_layer_fwd": (c_int, [c_void_p, c_void_p]),
     "vits_wn_layer_bwd": (c_int, [c_void_p, c_void_p]),
+    "vits_wn_pack_bytes": (c_size_t, [c_int] * 6),
+    "vits_wn_pack": (c_int, [c_void_p, c_int, c_void_p]),
     "vits_grouped_conv_fwd": (c_int, [c_int] + [c_void_p] * 4 + [c_int] * 8 + [c_float, c_void_p]),
     "vits_grouped_conv_dgrad": (c_int, [c_int] + [c_void_p] * 5 + [c_int] * 8 + [c_float, c_void_p]),
     "vits_grouped_conv_wgrad_workspace": (c_size_t, [c_int] * 5),
@@ -105,6 +109,11 @@ class WnLayerDesc(ctypes.Structure):
     """vits_wn_layer_desc of include/vitsmi.h"""
     _fields_ = [(n, ctypes.c_int32) for n in ("dtype", "b", "t", "h", "k", "dil", "last", "accumulate", "ldx", "ldh", "ldskip", "ldacts", "ldpre")] + \
                [(n, c_void_p) for n in ("x", "w_in", "b_in", "cond", "w_rs", "b_rs", "pre", "acts", "h_out", "skip", "lengths")]
+
+
+class WnPackSeg(ctypes.Structure):
+    """vits_wn_pack_seg of include/vitsmi.h"""
+    _fields_ = [("src", c_void_p), ("dst", c_void_p)] + [(n, ctypes.c_int32) for n in ("mode", "h", "rows", "rowbytes", "taps", "spt")]
 
 
 class WnLayerBwdDesc(ctypes.Structure):

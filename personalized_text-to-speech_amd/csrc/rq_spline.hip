@@ -28,19 +28,46 @@ template <typename T> __device__ __forceinline__ T from_f(float v);
 template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
 template <> __device__ __forceinline__ __bf16 from_f<__bf16>(float v) { return (__bf16)v; }
 
+// Transcendental VALU instructions with an explicit wait behind them.  gfx950 issues v_exp / v_log / v_rcp / v_sqrt at a quarter
+// of the VALU rate (four 16-lane passes) and does NOT interlock their result against the next VALU instruction (tools/hazard/
+// trans_hazard.hip: a dependent instruction directly behind v_rcp_f32 reads the stale register in every lane); hipcc pads a
+// dependent instruction with `s_nop 0`.  In this kernel that was not always enough: identical launches disagreed in lanes 48..63
+// — the last pass of a transcendental — of single waves, only while kernels of another stream shared the SIMDs (DESIGN.md §6b,
+// tools/dbg_spline_tap.py).  Every transcendental of this file therefore goes through these wrappers, which the compiler can
+// neither reorder nor pair up (the vectoriser had turned two divisions into back-to-back v_rcp_f32 feeding one v_pk_fma_f32),
+// and which keep VITS_TRANS_NOPS + 1 wait states between the instruction and any consumer.
+#ifndef VITS_TRANS_NOPS
+#define VITS_TRANS_NOPS 4
+#endif
+#define VITS_STR2(x) #x
+#define VITS_STR(x) VITS_STR2(x)
+#define VITS_TRANS(op, dst, src) asm volatile(op " %0, %1\n\ts_nop " VITS_STR(VITS_TRANS_NOPS) : "=v"(dst) : "v"(src))
+__device__ __forceinline__ float t_rcp(float x) { float r; VITS_TRANS("v_rcp_f32", r, x); return r; }
+__device__ __forceinline__ float t_exp2(float x) { float r; VITS_TRANS("v_exp_f32", r, x); return r; }
+__device__ __forceinline__ float t_log2(float x) { float r; VITS_TRANS("v_log_f32", r, x); return r; }
+__device__ __forceinline__ float t_sqrt(float x) { float r; VITS_TRANS("v_sqrt_f32", r, x); return r; }
+// e^x, ln x on the hardware's base-2 instructions (1 ulp each; arguments here are far from the denormal range: softmax exponents
+// are <= 0 and the smallest term is flushed harmlessly, logs take dnum / den > 0 of order 1e-3 .. 1e3)
+__device__ __forceinline__ float t_exp(float x) { return t_exp2(x * 1.44269504088896341f); }
+__device__ __forceinline__ float t_log(float x) { return t_log2(x) * 0.693147180559945309f; }
+
 // a / b as reciprocal estimate + one Newton step + one residual correction (error < 1 ulp for operands in the normal range, which
 // is all this kernel divides) instead of the v_div_scale / v_div_fmas / v_div_fixup sequence: 24 divisions per element, a third of
-// the kernel's instructions.  (Tried first as a cure for the kernel's irreproducibility next to other streams' kernels — it is
-// not: see the Makefile's FLAGS_rq_spline and DESIGN.md §6b.)
+// the kernel's instructions.
 __device__ __forceinline__ float fdiv(float a, float b) {
-  float r = __builtin_amdgcn_rcpf(b);
+  float r = t_rcp(b);
   r = fmaf(fmaf(-b, r, 1.0f), r, r);
   const float q = a * r;
   return fmaf(fmaf(-b, q, a), r, q);
 }
 
-__device__ __forceinline__ float softplus_f(float v) { return v > 20.f ? v : log1pf(expf(v)); }
-__device__ __forceinline__ float sigmoid_f(float v) { return fdiv(1.f, 1.f + expf(-v)); }
+// log(1 + e^v): v > 20 returns v (as torch's softplus threshold); e^v < 2^-24 adds nothing to 1 in fp32, the result is then e^v
+__device__ __forceinline__ float softplus_f(float v) {
+  if (v > 20.f) return v;
+  const float e = t_exp(v);
+  return e < 5.9604645e-8f ? e : t_log(1.f + e);
+}
+__device__ __forceinline__ float sigmoid_f(float v) { return fdiv(1.f, 1.f + t_exp(-v)); }
 
 struct Knots {
   float p[NB];        // softmax probabilities
@@ -53,7 +80,7 @@ __device__ __forceinline__ void make_knots(const float* u, float B, Knots& k) {
   for (int j = 1; j < NB; ++j) m = fmaxf(m, u[j]);
   float s = 0.f;
 #pragma unroll
-  for (int j = 0; j < NB; ++j) { k.p[j] = expf(u[j] - m); s += k.p[j]; }
+  for (int j = 0; j < NB; ++j) { k.p[j] = t_exp(u[j] - m); s += k.p[j]; }
   const float inv = fdiv(1.f, s);
   float cum = 0.f;
   k.c[0] = -B;
@@ -72,11 +99,20 @@ __device__ __forceinline__ void knots_bwd(const Knots& k, int i, float g_lo, flo
   const float glo = (i >= 1) ? g_lo : 0.f;
   const float ghi = (i + 1 <= NB - 1) ? g_hi : 0.f;
   float gp[NB], dot = 0.f;
+  float fi = (float)i;
+  asm volatile("" : "+v"(fi));          // opaque to the optimiser: it would prove fi integral and rebuild the compare + select
 #pragma unroll
   for (int m = 0; m < NB; ++m) {
+#ifdef VITS_SPLINE_MASK_SELECTS
     float gs = 0.f;
     if (m < i) gs += glo;
     if (m < i + 1) gs += ghi;
+#else
+    // [m < i] and [m <= i] as 0 / 1 factors clamp(i - m, 0, 1), clamp(i + 1 - m, 0, 1) on v_med3_f32: no per-lane select through
+    // an SGPR mask (the compiler turns every integer formulation of this back into v_cmp + v_cndmask)
+    const float lt = __builtin_amdgcn_fmed3f(fi - (float)m, 0.f, 1.f), le = __builtin_amdgcn_fmed3f(fi - (float)(m - 1), 0.f, 1.f);
+    const float gs = glo * lt + ghi * le;
+#endif
     gp[m] = 2.f * B * gs * (1.f - kMin * NB);
     dot += gp[m] * k.p[m];
   }
@@ -121,7 +157,9 @@ __global__ void spline_kernel(const float* __restrict__ x, const TH* __restrict_
   Knots kw, kh;
   make_knots(uw, B, kw);
   make_knots(uh, B, kh);
-  const float d_edge = kMin + softplus_f(logf(expf(1.f - kMin) - 1.f));
+  // the pinned end derivatives: min_derivative + softplus(log(exp(1 - min_derivative) - 1)) = 1 (transforms.py:79-82), folded at
+  // compile time with libm (no instruction is emitted for it)
+  const float d_edge = kMin + log1pf(expf(logf(expf(1.f - kMin) - 1.f)));
   // bin search on the widths' knots (forward) or the heights' knots (inverse); last edge + 1e-6
   const float* loc = inverse ? kh.c : kw.c;
   int i = -1;
@@ -149,7 +187,7 @@ __global__ void spline_kernel(const float* __restrict__ x, const TH* __restrict_
     a = u * s + Hh * (delta - d0);
     b = Hh * d0 - u * s;
     c = -delta * u;
-    sd = sqrtf(b * b - 4.f * a * c);
+    sd = t_sqrt(b * b - 4.f * a * c);
     D = -b - sd;
     theta = fdiv(2.f * c, D);
   }
@@ -158,7 +196,7 @@ __global__ void spline_kernel(const float* __restrict__ x, const TH* __restrict_
   const float E = d1 * theta * theta + 2.f * delta * q + d0 * (1.f - theta) * (1.f - theta);
   const float dnum = delta * delta * E;
   const float num = Hh * (delta * theta * theta + d0 * q);
-  const float l = logf(dnum) - 2.f * logf(den);
+  const float l = t_log(dnum) - 2.f * t_log(den);
   if (!inverse) out = CH + fdiv(num, den); else out = theta * W + CW;
   if (!BWD) {
     y[ix] = out * mv;

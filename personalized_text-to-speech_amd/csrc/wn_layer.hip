@@ -30,8 +30,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kThreads = 256;
-constexpr int TM = 64;            // time rows per workgroup
-constexpr int RT = TM / 32;       // row tiles per wave (every wave covers all rows)
 constexpr int D = 6;              // weight-fragment steps in flight per wave
 
 __device__ __forceinline__ float to_f(float v) { return v; }
@@ -61,7 +59,10 @@ __device__ __forceinline__ void mma_frag(f32x16& acc, const u32x4& av, const u32
   }
 }
 
-struct FwdArgs { vits_wn_layer_desc d; int pitch, xrows, spt, P1, P2; };
+struct FwdArgs { vits_wn_layer_desc d; int pitch, pitchP, xrows, spt, P1, P2; };
+
+// 16-byte vectors a thread holds when a workgroup stages `nvec` of them in one batch (all loads issued, then all LDS stores)
+constexpr int kStageMax = 10;
 
 // cooperative copy of `rows` rows x `rowbytes` bytes (16-byte vectors) from an LDS tile to global rows [t0, t0+rows) ∩ [0, t_hi)
 __device__ __forceinline__ void tile_to_global(const unsigned char* lds, int pitch, unsigned char* g, size_t ldg_bytes, int rowbytes,
@@ -73,11 +74,20 @@ __device__ __forceinline__ void tile_to_global(const unsigned char* lds, int pit
   }
 }
 
-template <typename T, int NT>
+// 16 bytes of T as floats and back
+template <typename T> struct Vec16 {
+  static constexpr int N = 16 / sizeof(T);
+  union { u32x4 u; T e[N]; };
+};
+
+// RT row tiles of 32 rows per workgroup: 2 in bf16; 1 in fp32, whose tiles are twice as large in LDS.
+template <typename T, int NT, int RT>
 __global__ __launch_bounds__(kThreads) void wn_layer_fwd_kernel(FwdArgs args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const vits_wn_layer_desc& a = args.d;
   constexpr int ES = sizeof(T);
+  constexpr int TM = 32 * RT;
+  constexpr int VN = 16 / ES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 31, h = lane >> 5;
   const int H = a.h, k = a.k, dil = a.dil;
@@ -85,63 +95,67 @@ __global__ __launch_bounds__(kThreads) void wn_layer_fwd_kernel(FwdArgs args) {
   const int t0 = blockIdx.x * TM, b = blockIdx.y;
   const int T_ = a.t;
   const int len = a.lengths ? (a.lengths[b] < T_ ? a.lengths[b] : T_) : T_;
-  const int pitch = args.pitch, spt = args.spt;          // spt = 32-byte fragment steps per tap = H * ES / 32
+  const int pitch = args.pitch, pitchP = args.pitchP, spt = args.spt;      // spt = 32-byte fragment steps per tap = H * ES / 32
   const int rowbytes = H * ES;
-  unsigned char* ldsX = smem;                            // [xrows][pitch]  h rows t0 - padr ...
-  unsigned char* ldsA = smem + (size_t)args.xrows * pitch;   // [TM][pitch]  gate outputs
+  unsigned char* ldsX = smem;                                   // [xrows][pitch]   h rows t0 - padr ...
+  unsigned char* ldsA = smem + (size_t)args.xrows * pitch;      // [TM][pitch]      gate outputs
+  unsigned char* ldsP = ldsA + (size_t)TM * pitch;              // [TM][pitchP]     pre-activations (T), later res | skip (fp32)
 
-  const int c_rs = a.last ? H : 2 * H;                   // rows of W_rs
+  const int c_rs = a.last ? H : 2 * H;                          // rows of W_rs
   const int S1 = k * spt, S2 = spt;
-  const int P1 = args.P1;                                // S1 rounded up to a multiple of D (dummy steps load, do not multiply)
+  const int P1 = args.P1;                                       // S1 rounded up to a multiple of D (dummy steps load, do not multiply)
 
-  // ---- per-lane weight row pointers (bytes): first product (gate-interleaved columns), second product (natural order)
+  // ---- per-lane fragment streams of the PACKED operands (vits_wn_pack: [column tile][step][lane][16 bytes], dead tiles zero):
+  // every wave-instruction below reads 1 KiB of consecutive memory
   const unsigned char* w1[NT];
   const unsigned char* w2[NT];
   bool live1[NT], live2[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     const int tile = wave * NT + n;
-    const int ch = 16 * tile + (c & 15);
     live1[n] = 16 * tile < H;
-    const int row1 = live1[n] ? (c < 16 ? ch : H + ch) : 0;
-    w1[n] = static_cast<const unsigned char*>(a.w_in) + (size_t)row1 * rowbytes + 16 * h;
-    const int co = 32 * tile + c;
     live2[n] = 32 * tile < c_rs;
-    w2[n] = static_cast<const unsigned char*>(a.w_rs) + (size_t)(co < c_rs ? co : 0) * rowbytes + 16 * h;
+    w1[n] = static_cast<const unsigned char*>(a.w_in) + ((size_t)tile * S1 * 64 + lane) * 16;
+    w2[n] = static_cast<const unsigned char*>(a.w_rs) + ((size_t)tile * S2 * 64 + lane) * 16;
   }
-  const size_t tap_stride = (size_t)2 * H * rowbytes;
 
   // fragment of step s (unified numbering: [0, P1) first product incl. dummies, [P1, P1 + P2) second product)
   auto load_step = [&](u32x4 (&dst)[NT], int s) {
     if (s < P1) {
-      const int sc = s < S1 ? s : S1 - 1;
-      const size_t off = (size_t)(sc / spt) * tap_stride + (size_t)(sc % spt) * 32;
+      const size_t off = (size_t)(s < S1 ? s : S1 - 1) * 1024;
 #pragma unroll
       for (int n = 0; n < NT; ++n) dst[n] = *reinterpret_cast<const u32x4*>(w1[n] + off);
     } else {
-      int s2 = s - P1;
-      s2 = s2 < S2 ? s2 : S2 - 1;
+      const int s2 = s - P1;
+      const size_t off = (size_t)(s2 < S2 ? s2 : S2 - 1) * 1024;
 #pragma unroll
-      for (int n = 0; n < NT; ++n) dst[n] = *reinterpret_cast<const u32x4*>(w2[n] + (size_t)s2 * 32);
+      for (int n = 0; n < NT; ++n) dst[n] = *reinterpret_cast<const u32x4*>(w2[n] + off);
     }
   };
 
+  // ---- stage the activation tile: all of a thread's loads first, then its LDS stores (rows outside [0, len) read as zero: the
+  // input is masked, modules.py:157 x * x_mask upstream)
+  {
+    const unsigned char* X = reinterpret_cast<const unsigned char*>(static_cast<const T*>(a.x) + (size_t)b * T_ * a.ldx);
+    const int vpr = rowbytes / 16, nvec = args.xrows * vpr;
+    u32x4 xv[kStageMax];
+#pragma unroll
+    for (int i = 0; i < kStageMax; ++i) {
+      const int idx = tid + i * kThreads, row = idx / vpr, v = idx % vpr;
+      const int t = t0 - padr + row;
+      u32x4 val = {0u, 0u, 0u, 0u};
+      if (idx < nvec && t >= 0 && t < len) val = *reinterpret_cast<const u32x4*>(X + (size_t)t * a.ldx * ES + v * 16);
+      xv[i] = val;
+    }
+#pragma unroll
+    for (int i = 0; i < kStageMax; ++i) {
+      const int idx = tid + i * kThreads;
+      if (idx < nvec) *reinterpret_cast<u32x4*>(ldsX + (idx / vpr) * pitch + (idx % vpr) * 16) = xv[i];
+    }
+  }
   u32x4 bq[D][NT];
 #pragma unroll
   for (int j = 0; j < D; ++j) load_step(bq[j], j);
-
-  // ---- stage the activation tile (rows outside [0, len) read as zero: the input is masked, modules.py:157 x * x_mask upstream)
-  {
-    const T* X = static_cast<const T*>(a.x) + (size_t)b * T_ * a.ldx;
-    const int vpr = rowbytes / 16;
-    for (int idx = tid; idx < args.xrows * vpr; idx += kThreads) {
-      const int row = idx / vpr, v = idx % vpr;
-      const int t = t0 - padr + row;
-      u32x4 val = {0u, 0u, 0u, 0u};
-      if (t >= 0 && t < len) val = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(X + (size_t)t * a.ldx) + v * 16);
-      *reinterpret_cast<u32x4*>(ldsX + row * pitch + v * 16) = val;
-    }
-  }
   __syncthreads();
 
   f32x16 acc[RT][NT];
@@ -152,64 +166,73 @@ __global__ __launch_bounds__(kThreads) void wn_layer_fwd_kernel(FwdArgs args) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[r][n][i] = 0.f;
 
-  // ---- first product: pre = conv_k(h)
-  for (int s0 = 0; s0 < P1; s0 += D) {
+  // ---- first product: pre = conv_k(h).  The input fragments of step s + 1 are read from LDS before step s multiplies (the LDS
+  // latency hides behind six MFMAs); (tap, m) of the next read advance as counters (no division by the runtime steps-per-tap).
+  static_assert(D % 2 == 0, "the fragment double buffer alternates with the unrolled step index");
+  {
+    const unsigned char* xbase = ldsX + c * pitch + 16 * h;
+    int tap_n = 0, m_n = 0;                               // (tap, 32-byte step inside the row) of the next fragment read
+    u32x4 av[2][RT];
+    auto read_a = [&](u32x4 (&dst)[RT]) {
+      const unsigned char* xa = xbase + tap_n * dil * pitch + 32 * m_n;
 #pragma unroll
-    for (int j = 0; j < D; ++j) {
-      const int s = s0 + j;
-      if (s < S1) {
-        const int tap = s / spt, m = s % spt;
-        const unsigned char* xa = ldsX + (c + tap * dil) * pitch + 32 * m + 16 * h;
-        u32x4 av[RT];
+      for (int r = 0; r < RT; ++r) dst[r] = *reinterpret_cast<const u32x4*>(xa + r * 32 * pitch);
+      if (++m_n == spt) { m_n = 0; ++tap_n; }
+    };
+    read_a(av[0]);
+    for (int s0 = 0; s0 < P1; s0 += D) {
 #pragma unroll
-        for (int r = 0; r < RT; ++r) av[r] = *reinterpret_cast<const u32x4*>(xa + r * 32 * pitch);
+      for (int j = 0; j < D; ++j) {
+        const int s = s0 + j;
+        if (s + 1 < S1) read_a(av[(j + 1) & 1]);
+        if (s < S1) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
+          for (int n = 0; n < NT; ++n)
 #pragma unroll
-          for (int r = 0; r < RT; ++r) mma_frag<T>(acc[r][n], av[r], bq[j][n]);
+            for (int r = 0; r < RT; ++r) mma_frag<T>(acc[r][n], av[j & 1][r], bq[j][n]);
+        }
+        load_step(bq[j], s + D);
       }
-      load_step(bq[j], s + D);
     }
   }
 
-  // ---- gate epilogue: lanes c and c + 16 hold the tanh / sigmoid pre-activations of one channel
-  {
-    T* PRE = a.pre ? static_cast<T*>(a.pre) + (size_t)b * T_ * a.ldpre : nullptr;
+  // ---- gate epilogue: lanes c and c + 16 hold the tanh / sigmoid pre-activations of one channel.  Everything goes to LDS tiles
+  // (pre as T, acts as T) and leaves for memory as 16-byte vectors afterwards.
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      if (!live1[n]) continue;
-      const int ch = 16 * (wave * NT + n) + (c & 15);
-      const bool lo = c < 16;
-      float ba = a.b_in ? a.b_in[ch] : 0.f, bb = a.b_in ? a.b_in[H + ch] : 0.f;
-      if (a.cond) { ba += a.cond[(size_t)b * 2 * H + ch]; bb += a.cond[(size_t)b * 2 * H + H + ch]; }
+  for (int n = 0; n < NT; ++n) {
+    if (!live1[n]) continue;
+    const int ch = 16 * (wave * NT + n) + (c & 15);
+    const bool lo = c < 16;
+    float ba = a.b_in ? a.b_in[ch] : 0.f, bb = a.b_in ? a.b_in[H + ch] : 0.f;
+    if (a.cond) { ba += a.cond[(size_t)b * 2 * H + ch]; bb += a.cond[(size_t)b * 2 * H + H + ch]; }
+    const float bias_own = lo ? ba : bb;
+    const int col = lo ? ch : H + ch;
 #pragma unroll
-      for (int r = 0; r < RT; ++r) {
-        if (PRE) {                                        // pre-activations as they stand (bias included), own column
-          const float bias_own = lo ? ba : bb;
-          const int col = lo ? ch : H + ch;
+    for (int r = 0; r < RT; ++r) {
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int t = t0 + r * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            if (t < T_) PRE[(size_t)t * a.ldpre + col] = from_f<T>(acc[r][n][i] + bias_own);
-          }
-        }
+      for (int i = 0; i < 16; ++i) {                     // pre-activations as they stand (bias included), own column
+        const int row = r * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        *reinterpret_cast<T*>(ldsP + row * pitchP + col * ES) = from_f<T>(acc[r][n][i] + bias_own);
+      }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          // low lanes evaluate registers 0..7 (they need the partner's register i), high lanes registers 8..15
-          const float send = lo ? acc[r][n][i + 8] : acc[r][n][i];
-          const float recv = __shfl_xor(send, 16, 64);
-          const float va = (lo ? acc[r][n][i] : recv) + ba;
-          const float vb = (lo ? recv : acc[r][n][i + 8]) + bb;
-          // the memory image of `pre` is in T: gate on the rounded values so that the backward (which re-reads `pre`) sees the same
-          const float ra = to_f(from_f<T>(va)), rb = to_f(from_f<T>(vb));
-          const int ii = lo ? i : i + 8;
-          const int row = r * 32 + (ii & 3) + 8 * (ii >> 2) + 4 * h;
-          *reinterpret_cast<T*>(ldsA + row * pitch + ch * ES) = from_f<T>(gate_tanh<T>(ra) * sigmoidf_(rb));
-        }
+      for (int i = 0; i < 8; ++i) {
+        // low lanes evaluate registers 0..7 (they need the partner's register i), high lanes registers 8..15
+        const float send = lo ? acc[r][n][i + 8] : acc[r][n][i];
+        const float recv = __shfl_xor(send, 16, 64);
+        const float va = (lo ? acc[r][n][i] : recv) + ba;
+        const float vb = (lo ? recv : acc[r][n][i + 8]) + bb;
+        // the memory image of `pre` is in T: gate on the rounded values so that the backward (which re-reads `pre`) sees the same
+        const float ra = to_f(from_f<T>(va)), rb = to_f(from_f<T>(vb));
+        const int ii = lo ? i : i + 8;
+        const int row = r * 32 + (ii & 3) + 8 * (ii >> 2) + 4 * h;
+        *reinterpret_cast<T*>(ldsA + row * pitch + ch * ES) = from_f<T>(gate_tanh<T>(ra) * sigmoidf_(rb));
       }
     }
   }
   __syncthreads();
+  if (a.pre)
+    tile_to_global(ldsP, pitchP, reinterpret_cast<unsigned char*>(static_cast<T*>(a.pre) + (size_t)b * T_ * a.ldpre), (size_t)a.ldpre * ES, 2 * rowbytes,
+                   TM, t0, T_);
   if (a.acts)
     tile_to_global(ldsA, pitch, reinterpret_cast<unsigned char*>(static_cast<T*>(a.acts) + (size_t)b * T_ * a.ldacts), (size_t)a.ldacts * ES, rowbytes,
                    TM, t0, T_);
@@ -222,74 +245,111 @@ __global__ __launch_bounds__(kThreads) void wn_layer_fwd_kernel(FwdArgs args) {
     for (int n = 0; n < NT; ++n)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc2[r][n][i] = 0.f;
-  for (int s0 = 0; s0 < args.P2; s0 += D) {
+  {
+    const unsigned char* abase = ldsA + c * pitch + 16 * h;
+    u32x4 av[2][RT];
 #pragma unroll
-    for (int j = 0; j < D; ++j) {
-      const int s = s0 + j;
-      if (s < S2) {
-        const unsigned char* xa = ldsA + c * pitch + 32 * s + 16 * h;
-        u32x4 av[RT];
+    for (int r = 0; r < RT; ++r) av[0][r] = *reinterpret_cast<const u32x4*>(abase + r * 32 * pitch);
+    for (int s0 = 0; s0 < args.P2; s0 += D) {
 #pragma unroll
-        for (int r = 0; r < RT; ++r) av[r] = *reinterpret_cast<const u32x4*>(xa + r * 32 * pitch);
+      for (int j = 0; j < D; ++j) {
+        const int s = s0 + j;
+        if (s + 1 < S2) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
+          for (int r = 0; r < RT; ++r) av[(j + 1) & 1][r] = *reinterpret_cast<const u32x4*>(abase + 32 * (s + 1) + r * 32 * pitch);
+        }
+        if (s < S2) {
 #pragma unroll
-          for (int r = 0; r < RT; ++r) mma_frag<T>(acc2[r][n], av[r], bq[j][n]);
+          for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < RT; ++r) mma_frag<T>(acc2[r][n], av[j & 1][r], bq[j][n]);
+        }
+        if (s + D < args.P2) load_step(bq[j], P1 + s + D);
       }
-      load_step(bq[j], P1 + s + D);
     }
   }
 
-  // ---- residual / skip epilogues
-  T* HO = a.h_out ? static_cast<T*>(a.h_out) + (size_t)b * T_ * a.ldh : nullptr;
-  T* SK = static_cast<T*>(a.skip) + (size_t)b * T_ * a.ldskip;
+  // ---- residual / skip epilogues: rs + bias as fp32 into the (now free) pre tile, then 16-byte vectors: h' = (h + res) * mask
+  // from the staged input rows, skip (+)= skip-half * mask with all the old values loaded before any is needed
+  __syncthreads();                                        // every thread is done copying the pre tile out
+  float* rsT = reinterpret_cast<float*>(ldsP);
+  const int pitchF = pitchP / 4;
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     if (!live2[n]) continue;
     const int co = 32 * (wave * NT + n) + c;
     if (co >= c_rs) continue;
     const float bias = a.b_rs ? a.b_rs[co] : 0.f;
-    const bool is_res = !a.last && co < H;
-    const int ch = is_res ? co : (a.last ? co : co - H);
 #pragma unroll
     for (int r = 0; r < RT; ++r)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int row = r * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        const int t = t0 + row;
-        if (t >= T_) continue;
-        const float v = acc2[r][n][i] + bias;
-        if (is_res) {
-          const float xin = to_f(*reinterpret_cast<const T*>(ldsX + (row + padr) * pitch + ch * ES));
-          if (HO) HO[(size_t)t * a.ldh + ch] = from_f<T>(t < len ? xin + v : 0.f);
-        } else {
-          const size_t o = (size_t)t * a.ldskip + ch;
-          const float m = t < len ? v : 0.f;
-          SK[o] = from_f<T>(a.accumulate ? to_f(SK[o]) + m : m);
+        rsT[row * pitchF + co] = acc2[r][n][i] + bias;
+      }
+  }
+  __syncthreads();
+  {
+    const int vpr = rowbytes / 16, nvec = TM * vpr;       // vectors of one H-channel half of the tile
+    constexpr int NV = (TM * 12 * (int)sizeof(T) + kThreads - 1) / kThreads;        // H <= 192: at most TM * 24 (bf16) / 48 (f32) vectors
+    if (!a.last && a.h_out) {
+      unsigned char* HO = reinterpret_cast<unsigned char*>(static_cast<T*>(a.h_out) + (size_t)b * T_ * a.ldh);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int idx = tid + i * kThreads, row = idx / vpr, v = idx % vpr, t = t0 + row;
+        if (idx < nvec && t < T_) {
+          Vec16<T> xin, out;
+          xin.u = *reinterpret_cast<const u32x4*>(ldsX + (row + padr) * pitch + v * 16);
+          const float* rp = rsT + row * pitchF + v * VN;
+#pragma unroll
+          for (int e = 0; e < VN; ++e) out.e[e] = from_f<T>(t < len ? to_f(xin.e[e]) + rp[e] : 0.f);
+          *reinterpret_cast<u32x4*>(HO + (size_t)t * a.ldh * ES + v * 16) = out.u;
         }
       }
+    }
+    unsigned char* SK = reinterpret_cast<unsigned char*>(static_cast<T*>(a.skip) + (size_t)b * T_ * a.ldskip);
+    const int sk0 = a.last ? 0 : H;                       // first column of the skip half in the rs tile
+    Vec16<T> old[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + i * kThreads, row = idx / vpr, v = idx % vpr, t = t0 + row;
+      old[i].u = u32x4{0u, 0u, 0u, 0u};
+      if (a.accumulate && idx < nvec && t < T_) old[i].u = *reinterpret_cast<const u32x4*>(SK + (size_t)t * a.ldskip * ES + v * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + i * kThreads, row = idx / vpr, v = idx % vpr, t = t0 + row;
+      if (idx < nvec && t < T_) {
+        const float* rp = rsT + row * pitchF + sk0 + v * VN;
+        Vec16<T> out;
+#pragma unroll
+        for (int e = 0; e < VN; ++e) out.e[e] = from_f<T>(to_f(old[i].e[e]) + (t < len ? rp[e] : 0.f));
+        *reinterpret_cast<u32x4*>(SK + (size_t)t * a.ldskip * ES + v * 16) = out.u;
+      }
+    }
   }
 }
 
-template <typename T, int NT>
+template <typename T, int NT, int RT>
 int launch_fwd(const vits_wn_layer_desc& d, hipStream_t s) {
   FwdArgs args;
   args.d = d;
-  const int es = sizeof(T);
+  const int es = sizeof(T), TM = 32 * RT;
   args.pitch = d.h * es + 16;
+  args.pitchP = 2 * d.h * 4 + 16;                          // fp32 [2H] rows (the pre tile in T fits inside)
   args.xrows = TM + (d.k - 1) * d.dil;
   args.spt = d.h * es / 32;
   args.P1 = vits::ceil_div(d.k * args.spt, D) * D;
   args.P2 = vits::ceil_div(args.spt, D) * D;
-  const size_t lds = (size_t)(args.xrows + TM) * args.pitch;
+  if (args.xrows * (d.h * es / 16) > kStageMax * kThreads) return VITS_E_UNSUPPORTED;
+  const size_t lds = (size_t)(args.xrows + TM) * args.pitch + (size_t)TM * args.pitchP;
   if (lds > (size_t)vits::kLdsBytesMax) return VITS_E_UNSUPPORTED;
-  auto kern = wn_layer_fwd_kernel<T, NT>;
+  auto kern = wn_layer_fwd_kernel<T, NT, RT>;
   { const hipError_t e = vits::ensure_max_dynamic_lds(reinterpret_cast<const void*>(kern)); if (e != hipSuccess) return vits::note_hip_error(e, "vits_wn_layer_fwd/attr"); }
   dim3 grid(vits::ceil_div(d.t, TM), d.b);
   hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, s, args);
   return vits::check_launch("vits_wn_layer_fwd");
 }
-
 
 // =============================================================================================================================
 // backward: 16x16 tiles so that the four waves split H = 192 output channels evenly (48 = 3 column tiles each) in BOTH products.
@@ -330,42 +390,33 @@ __global__ __launch_bounds__(kThreads) void wn_layer_bwd_kernel(BwdArgs args) {
   const int T_ = a.t;
   const int len = a.lengths ? (a.lengths[b] < T_ ? a.lengths[b] : T_) : T_;
   const int pitch = args.pitch;
-  const int K1 = a.last ? H : 2 * H;                      // reduction depth of the first product (channels of [d_h | d_o])
-  const int k1bytes = K1 * ES, rowbytes2 = 2 * H * ES;
+  const int rowbytes2 = 2 * H * ES;
   unsigned char* ldsD = smem;                               // [R][pitch]          [d_h | d_o] rows t0 - pad ...
   unsigned char* ldsP = smem + (size_t)R * pitch;           // [R + halo][pitch]   pre -> d_pre (rows >= R zero)
 
   const int S1 = args.S1, spt = args.spt, P1 = args.P1;     // S1 = ceil(k1bytes / 64); spt = rowbytes2 / 64 steps per tap
   const int S2 = k * spt;
 
+  // packed data-gradient operands (vits_wn_pack mode 2: [16-channel tile][step][lane][16 bytes], tails and dead tiles zero)
   const unsigned char* w1[NT];
   const unsigned char* w2[NT];
   bool live[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
-    const int ch = (wave * NT + n) * 16 + c;
-    live[n] = (wave * NT + n) * 16 < H;
-    const int row = live[n] ? ch : 0;
-    w1[n] = static_cast<const unsigned char*>(a.w_rs_t) + (size_t)row * k1bytes + 16 * q;
-    w2[n] = static_cast<const unsigned char*>(a.w_in_t) + (size_t)row * rowbytes2 + 16 * q;
+    const int tile = wave * NT + n;
+    live[n] = tile * 16 < H;
+    w1[n] = static_cast<const unsigned char*>(a.w_rs_t) + ((size_t)tile * S1 * 64 + lane) * 16;
+    w2[n] = static_cast<const unsigned char*>(a.w_in_t) + ((size_t)tile * S2 * 64 + lane) * 16;
   }
-  const size_t tap_stride = (size_t)H * rowbytes2;
 
   auto load_step = [&](u32x4 (&dst)[NT], int s) {
     if (s < P1) {
-      const int sc = s < S1 ? s : S1 - 1;
-      const bool ok = 64 * sc + 16 * q < k1bytes;           // a row of W_rs^T may end inside the last 64-byte step (H = 16, bf16)
-      const size_t off = ok ? (size_t)sc * 64 : 0;
+      const size_t off = (size_t)(s < S1 ? s : S1 - 1) * 1024;
 #pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(w1[n] + off - (ok ? 0 : 16 * q));
-        const u32x4 z = {0u, 0u, 0u, 0u};
-        dst[n] = ok ? v : z;
-      }
+      for (int n = 0; n < NT; ++n) dst[n] = *reinterpret_cast<const u32x4*>(w1[n] + off);
     } else {
-      int s2 = s - P1;
-      s2 = s2 < S2 ? s2 : S2 - 1;
-      const size_t off = (size_t)(s2 / spt) * tap_stride + (size_t)(s2 % spt) * 64;
+      const int s2 = s - P1;
+      const size_t off = (size_t)(s2 < S2 ? s2 : S2 - 1) * 1024;
 #pragma unroll
       for (int n = 0; n < NT; ++n) dst[n] = *reinterpret_cast<const u32x4*>(w2[n] + off);
     }
@@ -375,26 +426,36 @@ __global__ __launch_bounds__(kThreads) void wn_layer_bwd_kernel(BwdArgs args) {
 #pragma unroll
   for (int j = 0; j < D; ++j) load_step(bq[j], j);
 
-  // ---- stage [d_h | d_o] and pre (rows outside [0, T) zero)
+  // ---- stage [d_h | d_o] and pre (rows outside [0, T) zero): batches of kStageMax vectors per thread, loads first, LDS stores after
   {
     const int vh = H * ES / 16;                             // 16-byte vectors per H-channel half-row
     const unsigned char* DH = a.d_h ? reinterpret_cast<const unsigned char*>(static_cast<const T*>(a.d_h) + (size_t)b * T_ * a.ld_dh) : nullptr;
     const unsigned char* DO = reinterpret_cast<const unsigned char*>(static_cast<const T*>(a.d_o) + (size_t)b * T_ * a.ld_do);
     const unsigned char* PR = reinterpret_cast<const unsigned char*>(static_cast<const T*>(a.pre) + (size_t)b * T_ * a.ldpre);
-    const int vpr = 2 * vh;
-    for (int idx = tid; idx < (R + halo) * vpr; idx += kThreads) {
-      const int row = idx / vpr, v = idx % vpr;
-      const int t = t0 - pad + row;
-      const bool in = row < R && t >= 0 && t < T_;
-      u32x4 pv = {0u, 0u, 0u, 0u}, dv = {0u, 0u, 0u, 0u};
-      if (in) {
-        pv = *reinterpret_cast<const u32x4*>(PR + (size_t)t * a.ldpre * ES + v * 16);
-        if (a.last) { if (v < vh) dv = *reinterpret_cast<const u32x4*>(DO + (size_t)t * a.ld_do * ES + v * 16); }
-        else if (v < vh) dv = *reinterpret_cast<const u32x4*>(DH + (size_t)t * a.ld_dh * ES + v * 16);
-        else dv = *reinterpret_cast<const u32x4*>(DO + (size_t)t * a.ld_do * ES + (v - vh) * 16);
+    const int vpr = 2 * vh, nvec = (R + halo) * vpr;
+    for (int base = 0; base < nvec; base += kStageMax / 2 * kThreads) {
+      u32x4 pv[kStageMax / 2], dv[kStageMax / 2];
+#pragma unroll
+      for (int i = 0; i < kStageMax / 2; ++i) {
+        const int idx = base + tid + i * kThreads, row = idx / vpr, v = idx % vpr;
+        const int t = t0 - pad + row;
+        const bool in = idx < nvec && row < R && t >= 0 && t < T_;
+        pv[i] = dv[i] = u32x4{0u, 0u, 0u, 0u};
+        if (in) {
+          pv[i] = *reinterpret_cast<const u32x4*>(PR + (size_t)t * a.ldpre * ES + v * 16);
+          if (a.last) { if (v < vh) dv[i] = *reinterpret_cast<const u32x4*>(DO + (size_t)t * a.ld_do * ES + v * 16); }
+          else if (v < vh) dv[i] = *reinterpret_cast<const u32x4*>(DH + (size_t)t * a.ld_dh * ES + v * 16);
+          else dv[i] = *reinterpret_cast<const u32x4*>(DO + (size_t)t * a.ld_do * ES + (v - vh) * 16);
+        }
       }
-      *reinterpret_cast<u32x4*>(ldsP + row * pitch + v * 16) = pv;
-      if (row < R) *reinterpret_cast<u32x4*>(ldsD + row * pitch + v * 16) = dv;
+#pragma unroll
+      for (int i = 0; i < kStageMax / 2; ++i) {
+        const int idx = base + tid + i * kThreads, row = idx / vpr, v = idx % vpr;
+        if (idx < nvec) {
+          *reinterpret_cast<u32x4*>(ldsP + row * pitch + v * 16) = pv[i];
+          if (row < R) *reinterpret_cast<u32x4*>(ldsD + row * pitch + v * 16) = dv[i];
+        }
+      }
     }
   }
   __syncthreads();
@@ -405,22 +466,28 @@ __global__ __launch_bounds__(kThreads) void wn_layer_bwd_kernel(BwdArgs args) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[r][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- first product: d_acts = [d_h | d_o] . W_rs
-  for (int s0 = 0; s0 < P1; s0 += D) {
+  // ---- first product: d_acts = [d_h | d_o] . W_rs (fragments of step s + 1 read from LDS before step s multiplies)
+  {
+    const unsigned char* dbase = ldsD + c * pitch + 16 * q;
+    u32x4 av[2][RTILES];
 #pragma unroll
-    for (int j = 0; j < D; ++j) {
-      const int s = s0 + j;
-      if (s < S1) {
-        const unsigned char* xa = ldsD + c * pitch + 64 * s + 16 * q;
-        u32x4 av[RTILES];
+    for (int r = 0; r < RTILES; ++r) av[0][r] = *reinterpret_cast<const u32x4*>(dbase + r * 16 * pitch);
+    for (int s0 = 0; s0 < P1; s0 += D) {
 #pragma unroll
-        for (int r = 0; r < RTILES; ++r) av[r] = *reinterpret_cast<const u32x4*>(xa + r * 16 * pitch);
+      for (int j = 0; j < D; ++j) {
+        const int s = s0 + j;
+        if (s + 1 < S1) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
+          for (int r = 0; r < RTILES; ++r) av[(j + 1) & 1][r] = *reinterpret_cast<const u32x4*>(dbase + 64 * (s + 1) + r * 16 * pitch);
+        }
+        if (s < S1) {
 #pragma unroll
-          for (int r = 0; r < RTILES; ++r) mma16<T>(acc[r][n], av[r], bq[j][n]);
+          for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < RTILES; ++r) mma16<T>(acc[r][n], av[j & 1][r], bq[j][n]);
+        }
+        load_step(bq[j], s + D);
       }
-      load_step(bq[j], s + D);
     }
   }
 
@@ -461,27 +528,35 @@ __global__ __launch_bounds__(kThreads) void wn_layer_bwd_kernel(BwdArgs args) {
   for (int r = 0; r < RTILES; ++r)
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc2[r][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int s0 = 0; s0 < args.P2; s0 += D) {
+  {
+    const unsigned char* pbase = ldsP + c * pitch + 16 * q;
+    int tap_n = 0, m_n = 0;                                // (tap, 64-byte step inside the row) of the next fragment read
+    u32x4 av[2][RTILES];
+    auto read_a = [&](u32x4 (&dst)[RTILES]) {
+      const unsigned char* xa = pbase + tap_n * dil * pitch + 64 * m_n;
 #pragma unroll
-    for (int j = 0; j < D; ++j) {
-      const int s = s0 + j;
-      if (s < S2) {
-        const int tap = s / spt, m = s % spt;
-        const unsigned char* xa = ldsP + (c + tap * dil) * pitch + 64 * m + 16 * q;
-        u32x4 av[RTILES];
+      for (int r = 0; r < RTILES; ++r) dst[r] = *reinterpret_cast<const u32x4*>(xa + r * 16 * pitch);
+      if (++m_n == spt) { m_n = 0; ++tap_n; }
+    };
+    read_a(av[0]);
+    for (int s0 = 0; s0 < args.P2; s0 += D) {
 #pragma unroll
-        for (int r = 0; r < RTILES; ++r) av[r] = *reinterpret_cast<const u32x4*>(xa + r * 16 * pitch);
+      for (int j = 0; j < D; ++j) {
+        const int s = s0 + j;
+        if (s + 1 < S2) read_a(av[(j + 1) & 1]);
+        if (s < S2) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
+          for (int n = 0; n < NT; ++n)
 #pragma unroll
-          for (int r = 0; r < RTILES; ++r) mma16<T>(acc2[r][n], av[r], bq[j][n]);
+            for (int r = 0; r < RTILES; ++r) mma16<T>(acc2[r][n], av[j & 1][r], bq[j][n]);
+        }
+        if (s + D < args.P2) load_step(bq[j], P1 + s + D);
       }
-      if (s + D < args.P2) load_step(bq[j], P1 + s + D);
     }
   }
 
-  // ---- d_h' = (d_h + conv^T) * mask
-  T* OUT = static_cast<T*>(a.d_h_out) + (size_t)b * T_ * a.ldout;
+  // ---- d_h' = (d_h + conv^T) * mask: summed in fp32, rounded once, into the (now free) d_pre tile, then 16-byte vector stores
+  __syncthreads();                                         // every wave is done reading the d_pre tile
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     if (!live[n]) continue;
@@ -491,13 +566,15 @@ __global__ __launch_bounds__(kThreads) void wn_layer_bwd_kernel(BwdArgs args) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int j = 16 * r + 4 * q + i;
-        const int t = t0 + j;
-        if (j >= TOUT || t >= T_) continue;
+        if (j >= TOUT) continue;
         float v = acc2[r][n][i];
         if (!a.last) v += to_f(*(reinterpret_cast<const T*>(ldsD + (j + pad) * pitch) + ch));
-        OUT[(size_t)t * a.ldout + ch] = from_f<T>(t < len ? v : 0.f);
+        *(reinterpret_cast<T*>(ldsP + j * pitch) + ch) = from_f<T>(t0 + j < len ? v : 0.f);
       }
   }
+  __syncthreads();
+  tile_to_global(ldsP, pitch, reinterpret_cast<unsigned char*>(static_cast<T*>(a.d_h_out) + (size_t)b * T_ * a.ldout), (size_t)a.ldout * ES, H * ES, TOUT, t0,
+                 T_);
 }
 
 template <typename T, int RTILES, int NT>
@@ -520,6 +597,51 @@ int launch_bwd(const vits_wn_layer_bwd_desc& d, hipStream_t s) {
   return vits::check_launch("vits_wn_layer_bwd");
 }
 
+
+// =============================================================================================================================
+// Operand packing: re-orders the arena's operands of a stack's layers into the order the kernels above consume them — per column
+// tile and reduction step the 64 lanes' 16-byte MFMA fragments back to back — so that every weight load of a wave is 1 KiB of
+// consecutive memory (loaded straight from the [c_out][c_in] rows a fragment load touches 32 cache lines for 32 bytes each, and
+// the four k-steps that share those lines are a whole prefetch ring apart: measured 77 us per layer instead of ~10).
+// One launch per stack per forward (the operands change with every optimizer step).
+constexpr int kMaxPack = 64;
+struct PackTable { vits_wn_pack_seg e[kMaxPack]; unsigned first[kMaxPack + 1]; int n; };
+
+__global__ void wn_pack_kernel(PackTable tab) {
+  const unsigned v = blockIdx.x * blockDim.x + threadIdx.x;                // destination 16-byte vector, over all segments
+  if (v >= tab.first[tab.n]) return;
+  int ei = 0;
+#pragma unroll 1
+  for (int i = 1; i < tab.n; ++i) if (v >= tab.first[i]) ei = i;
+  const vits_wn_pack_seg& g = tab.e[ei];
+  const unsigned lv = v - tab.first[ei];
+  const int lane = lv & 63;
+  const unsigned rest = lv >> 6;
+  const int steps = g.taps * g.spt;
+  const int s = rest % steps, tile = rest / steps;
+  const int tap = s / g.spt, m = s % g.spt;
+  int row, off;
+  bool ok;
+  if (g.mode == 2) {                                                        // 16-row tiles, 64-byte steps
+    const int c = lane & 15, q = lane >> 4;
+    row = 16 * tile + c; off = 64 * m + 16 * q;
+    ok = row < g.rows && off < g.rowbytes;
+  } else {
+    const int c = lane & 31, h = lane >> 5;
+    off = 32 * m + 16 * h;
+    if (g.mode == 0) {                                                      // gate interleave: 16 tanh rows | their 16 sigmoid rows
+      const int ch = 16 * tile + (c & 15);
+      ok = 16 * tile < g.h; row = c < 16 ? ch : g.h + ch;
+    } else {
+      row = 32 * tile + c; ok = row < g.rows;
+    }
+    ok = ok && off < g.rowbytes;
+  }
+  u32x4 val = {0u, 0u, 0u, 0u};
+  if (ok) val = *reinterpret_cast<const u32x4*>(static_cast<const unsigned char*>(g.src) + (size_t)tap * g.rows * g.rowbytes + (size_t)row * g.rowbytes + off);
+  *reinterpret_cast<u32x4*>(static_cast<unsigned char*>(g.dst) + (size_t)lv * 16) = val;
+}
+
 }  // namespace
 
 extern "C" int vits_wn_layer_fwd(const vits_wn_layer_desc* desc, void* stream) {
@@ -539,13 +661,13 @@ extern "C" int vits_wn_layer_fwd(const vits_wn_layer_desc* desc, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int nt = vits::ceil_div(d.h, 64);
   if (d.dtype == VITS_DT_BF16) {
-    if (nt == 1) return launch_fwd<__bf16, 1>(d, s);
-    if (nt == 2) return launch_fwd<__bf16, 2>(d, s);
-    return launch_fwd<__bf16, 3>(d, s);
+    if (nt == 1) return launch_fwd<__bf16, 1, 2>(d, s);
+    if (nt == 2) return launch_fwd<__bf16, 2, 2>(d, s);
+    return launch_fwd<__bf16, 3, 2>(d, s);
   }
-  if (nt == 1) return launch_fwd<float, 1>(d, s);
-  if (nt == 2) return launch_fwd<float, 2>(d, s);
-  return launch_fwd<float, 3>(d, s);
+  if (nt == 1) return launch_fwd<float, 1, 1>(d, s);
+  if (nt == 2) return launch_fwd<float, 2, 1>(d, s);
+  return launch_fwd<float, 3, 1>(d, s);
 }
 
 extern "C" int vits_wn_layer_bwd(const vits_wn_layer_bwd_desc* desc, void* stream) {
@@ -574,4 +696,34 @@ extern "C" int vits_wn_layer_bwd(const vits_wn_layer_bwd_desc* desc, void* strea
   if (nt == 1) return launch_bwd<float, 2, 1>(d, s);
   if (nt == 2) return launch_bwd<float, 2, 2>(d, s);
   return launch_bwd<float, 2, 3>(d, s);
+}
+
+extern "C" size_t vits_wn_pack_bytes(int mode, int dtype, int h, int rows, int k_elems, int taps) {
+  const int es = dtype == VITS_DT_BF16 ? 2 : 4;
+  const int nt = vits::ceil_div(h, 64);
+  const int spt = mode == 2 ? vits::ceil_div(k_elems * es, 64) : k_elems * es / 32;
+  (void)rows;
+  return (size_t)4 * nt * taps * spt * 1024;
+}
+
+extern "C" int vits_wn_pack(const vits_wn_pack_seg* segs, int count, void* stream) {
+  if (!segs || count <= 0) return VITS_E_BADARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  for (int i0 = 0; i0 < count; i0 += kMaxPack) {
+    PackTable tab;
+    tab.n = count - i0 < kMaxPack ? count - i0 : kMaxPack;
+    unsigned total = 0;
+    for (int j = 0; j < tab.n; ++j) {
+      const vits_wn_pack_seg& g = segs[i0 + j];
+      if (!g.src || !g.dst || g.mode < 0 || g.mode > 2 || g.h <= 0 || g.h % 16 != 0 || g.h > 192 || g.rows <= 0 || g.rowbytes <= 0 || g.taps <= 0 ||
+          g.spt <= 0 || g.rowbytes % 16 != 0)
+        return VITS_E_BADARG;
+      tab.e[j] = g;
+      tab.first[j] = total;
+      total += (unsigned)(4 * vits::ceil_div(g.h, 64) * g.taps * g.spt * 64);
+    }
+    tab.first[tab.n] = total;
+    hipLaunchKernelGGL(wn_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, s, tab);
+  }
+  return vits::check_launch("vits_wn_pack");
 }

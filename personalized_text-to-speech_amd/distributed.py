@@ -42,13 +42,17 @@ class GradBuckets:
     communication stream while backward continues.  With a single process there is nothing to
     exchange and the buckets are never packed."""
 
-    def __init__(self, params, bucket_bytes=64 << 20, group=None):
+    def __init__(self, params, bucket_bytes=64 << 20, group=None, force=False):
+        """force: build the buckets and run the pack / all-reduce path even with ONE rank (an initialised process group is
+        still required): the averaging is then the identity, but every RCCL call of the N > 1 path executes — how a one-GPU
+        box exercises and times it (tests/test_rccl_single_gpu.py, bench.py --exchange)."""
         self.params = [p for p in params if p.requires_grad]
         self.group = group
         self.world = world()
+        self.active = self.world > 1 or (force and dist.is_available() and dist.is_initialized())
         self.buckets = []          # (flat tensor, [params], [views])
         self._bucket_of = {}
-        if self.world > 1:
+        if self.active:
             cur, cur_bytes = [], 0
             for p in reversed(self.params):      # reverse registration order ~ order backward produces gradients
                 nbytes = p.numel() * p.element_size()

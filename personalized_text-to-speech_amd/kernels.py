@@ -247,7 +247,7 @@ def _stft_ri(y, n_fft, hop, win, window, prepadded=False):
     yp = yp.float()
     if tp < need:
         yp = F.pad(yp, (0, need - tp))
-    x = yp[:, :need].reshape(b, rows, hop)
+    x = yp[:, :need].contiguous().reshape(b, rows, hop)            # (a no-op unless the padded signal is longer than the frames cover)
     op = _dft_operand(n_fft, hop, window.float())
     ri = wn_cl.conv_cl(x, op, dtype=torch.float32)                     # [b, frames, 2*Fp]
     return ri, n_fft // 2 + 1, op.size(1) // 2
@@ -382,18 +382,72 @@ def conv1d_cl_raw(x, w, bias=None, bias_b=None, res=None, mg_src=None, out=None,
     return out
 
 
-def wn_layer_fwd(x, w_in, b_in, cond, w_rs, b_rs, lengths, dil, skip, accumulate, last, pre=None, acts=None):
+class WnPacked:
+    """The operands of a WaveNet stack in the fragment order vits_wn_layer_fwd / _bwd read (vits_wn_pack, csrc/wn_layer.hip):
+    one persistent buffer per (stack, dtype), re-filled by ONE launch per forward (the weights change with every optimizer
+    step); the backward of the same step reads the data-gradient operands packed by that launch."""
+
+    def __init__(self, H, k, L, dtype, device):
+        lib = _lib.lib()
+        dt = _DT[dtype]
+        self.H, self.k, self.L, self.dtype = H, k, L, dtype
+        self.es = torch.empty((), dtype=dtype).element_size()
+        size = lambda mode, rows, kel, taps: lib.vits_wn_pack_bytes(mode, dt, H, rows, kel, taps)
+        self.off, total = [], 0
+        for i in range(L):
+            c_rs = H if i == L - 1 else 2 * H
+            sizes = (size(0, 2 * H, H, k), size(1, c_rs, H, 1), size(2, H, c_rs, 1), size(2, H, 2 * H, k))
+            offs = []
+            for n in sizes:
+                offs.append(total)
+                total += n
+            self.off.append(offs)
+        self.buf = torch.empty(total, dtype=torch.uint8, device=device)
+        self.with_bwd = False
+
+    def ptr(self, layer, which):
+        return self.buf.data_ptr() + self.off[layer][which]
+
+    def fill(self, fwd_ops, bwd_ops):
+        """fwd_ops[i] = (w_in [k][2H][H], w_rs [1][2H|H][H]); bwd_ops[i] = (w_rs_t [1][H][2H|H], w_in_t [k][H][2H]) or None."""
+        import ctypes
+        H, k, es = self.H, self.k, self.es
+        segs = []
+        for i, (w_in, w_rs) in enumerate(fwd_ops):
+            c_rs = w_rs.size(1)
+            assert w_in.is_contiguous() and w_rs.is_contiguous() and tuple(w_in.shape) == (k, 2 * H, H) and w_rs.size(2) == H
+            segs.append((w_in.data_ptr(), self.ptr(i, 0), 0, H, 2 * H, H * es, k, H * es // 32))
+            segs.append((w_rs.data_ptr(), self.ptr(i, 1), 1, H, c_rs, H * es, 1, H * es // 32))
+            if bwd_ops is not None:
+                w_rs_t, w_in_t = bwd_ops[i]
+                assert w_rs_t.is_contiguous() and w_in_t.is_contiguous() and tuple(w_in_t.shape) == (k, H, 2 * H) and tuple(w_rs_t.shape) == (1, H, c_rs)
+                segs.append((w_rs_t.data_ptr(), self.ptr(i, 2), 2, H, H, c_rs * es, 1, (c_rs * es + 63) // 64))
+                segs.append((w_in_t.data_ptr(), self.ptr(i, 3), 2, H, H, 2 * H * es, k, 2 * H * es // 64))
+        arr = (_lib.WnPackSeg * len(segs))()
+        for a, (src, dst, mode, h, rows, rowbytes, taps, spt) in zip(arr, segs):
+            a.src, a.dst, a.mode, a.h, a.rows, a.rowbytes, a.taps, a.spt = src, dst, mode, h, rows, rowbytes, taps, spt
+        _lib.check(_lib.lib().vits_wn_pack(ctypes.addressof(arr), len(segs), _lib.stream_ptr()), "vits_wn_pack")
+        self.with_bwd = bwd_ops is not None
+
+
+def wn_fusable(H, k, dil_max=1, es=2):
+    """Shapes vits_wn_layer_fwd / _bwd take (else the caller composes the layer from convolution launches): the gate
+    interleave's granularity, 4 waves x 3 column tiles, and a (k-1)*dil halo that fits the staged row tile (64 rows in bf16, 32
+    in fp32) and the forward's one-batch staging of it."""
+    rows = 64 if es == 2 else 32
+    halo = (k - 1) * dil_max
+    return H % 16 == 0 and H <= 192 and k % 2 == 1 and halo < rows and (rows + halo) * (H * es // 16) <= 2560
+
+
+def wn_layer_fwd(x, packed, layer, b_in, cond, b_rs, lengths, dil, skip, accumulate, last, pre=None, acts=None):
     """One WaveNet layer in one launch (csrc/wn_layer.hip, vits_wn_layer_fwd; reference modules.py:157-176): x [b,t,H] with rows
-    >= lengths zero, w_in [k][2H][H] / w_rs [1][2H|H][H] in x's dtype, b_in / b_rs fp32, cond fp32 [b][2H] or None.
+    >= lengths zero, `packed` the stack's WnPacked operands (filled this forward), b_in / b_rs fp32, cond fp32 [b][2H] or None.
     Writes pre [b,t,2H] / acts [b,t,H] when given, accumulates the skip half into `skip`, returns h_out (None for the last
-    layer).  Returns NotImplemented when the kernel does not take the shape (the caller composes the layer from conv launches)."""
-    _lib.require_cuda(x, w_in, w_rs, skip)
+    layer)."""
+    _lib.require_cuda(x, skip)
     b, t, H = x.shape
-    k = w_in.size(0)
-    if H % 16 != 0 or H > 192 or k % 2 == 0:
-        return NotImplemented
-    assert w_in.dtype == x.dtype and w_rs.dtype == x.dtype and w_in.is_contiguous() and w_rs.is_contiguous()
-    assert tuple(w_in.shape) == (k, 2 * H, H) and tuple(w_rs.shape) == (1, H if last else 2 * H, H), (tuple(w_in.shape), tuple(w_rs.shape))
+    k = packed.k
+    assert wn_fusable(H, k) and packed.H == H and packed.dtype == x.dtype
     for tns in (b_in, b_rs, cond):
         assert tns is None or (tns.dtype == torch.float32 and tns.is_contiguous())
     assert cond is None or tuple(cond.shape) == (b, 2 * H)
@@ -405,7 +459,7 @@ def wn_layer_fwd(x, w_in, b_in, cond, w_rs, b_rs, lengths, dil, skip, accumulate
     d = _lib.WnLayerDesc(dtype=_DT[x.dtype], b=b, t=t, h=H, k=k, dil=dil, last=int(bool(last)), accumulate=int(bool(accumulate)),
                          ldx=_rows(x, "x"), ldh=H, ldskip=_rows(skip, "skip"), ldacts=0 if acts is None else _rows(acts, "acts"),
                          ldpre=0 if pre is None else _rows(pre, "pre"),
-                         x=x.data_ptr(), w_in=w_in.data_ptr(), b_in=p(b_in), cond=p(cond), w_rs=w_rs.data_ptr(), b_rs=p(b_rs),
+                         x=x.data_ptr(), w_in=packed.ptr(layer, 0), b_in=p(b_in), cond=p(cond), w_rs=packed.ptr(layer, 1), b_rs=p(b_rs),
                          pre=p(pre), acts=p(acts), h_out=p(h_out), skip=skip.data_ptr(), lengths=p(lengths))
     import ctypes
     e0 = _lib.timer.start("vits_wn_layer_fwd")
@@ -417,26 +471,21 @@ def wn_layer_fwd(x, w_in, b_in, cond, w_rs, b_rs, lengths, dil, skip, accumulate
                                                    es * (b * t * H * (2 + (0 if last else 1) + (1 if accumulate else 0) + (2 if pre is not None else 0)
                                                                       + (1 if acts is not None else 0)) + (2 * k + c_rs // H) * H * H)),
                         shape=f"b{b} t{t} H{H} k{k} d{dil} last{int(bool(last))} {str(x.dtype)[6:]}")
-    if rc == _lib.E_UNSUPPORTED:
-        return NotImplemented
     _lib.check(rc, "vits_wn_layer_fwd")
     return h_out
 
 
-def wn_layer_bwd(d_h, d_o, pre, w_rs_t, w_in_t, lengths, dil, last, d_pre, d_h_out):
+def wn_layer_bwd(d_h, d_o, pre, packed, layer, lengths, dil, last, d_pre, d_h_out):
     """Data-gradient half of one WaveNet layer's backward in one launch (csrc/wn_layer.hip, vits_wn_layer_bwd):
     d_pre = gate'(pre) * ([d_h | d_o] . W_rs) (masked) into `d_pre` [b,t,2H]; d_h_out = (d_h + conv^T(d_pre; W_in)) * mask.
-    d_h / d_o / d_h_out [b,t,H] may be column slices of wider tensors; w_rs_t [1][H][2H|H], w_in_t [k][H][2H] are the arena's
-    data-gradient operands.  Returns False when the kernel does not take the shape."""
-    _lib.require_cuda(d_o, pre, w_rs_t, w_in_t, d_pre, d_h_out)
+    d_h / d_o / d_h_out [b,t,H] may be column slices of wider tensors; `packed` holds the data-gradient operands packed by this
+    step's forward (WnPacked.fill)."""
+    _lib.require_cuda(d_o, pre, d_pre, d_h_out)
     b, t, H = d_o.shape
-    k = w_in_t.size(0)
-    if H % 16 != 0 or H > 192 or k % 2 == 0:
-        return False
+    k = packed.k
     dt = d_o.dtype
-    assert all(x.dtype == dt for x in (pre, w_rs_t, w_in_t, d_pre, d_h_out)) and (d_h is None or d_h.dtype == dt)
-    assert w_rs_t.is_contiguous() and w_in_t.is_contiguous()
-    assert tuple(w_in_t.shape) == (k, H, 2 * H) and tuple(w_rs_t.shape) == (1, H, H if last else 2 * H), (tuple(w_in_t.shape), tuple(w_rs_t.shape))
+    assert wn_fusable(H, k) and packed.H == H and packed.dtype == dt and packed.with_bwd
+    assert all(x.dtype == dt for x in (pre, d_pre, d_h_out)) and (d_h is None or d_h.dtype == dt)
     assert tuple(pre.shape) == (b, t, 2 * H) and tuple(d_pre.shape) == (b, t, 2 * H) and tuple(d_h_out.shape) == (b, t, H)
     assert last or tuple(d_h.shape) == (b, t, H)
     assert lengths is None or lengths.dtype == torch.int32
@@ -444,8 +493,8 @@ def wn_layer_bwd(d_h, d_o, pre, w_rs_t, w_in_t, lengths, dil, last, d_pre, d_h_o
     d = _lib.WnLayerBwdDesc(dtype=_DT[dt], b=b, t=t, h=H, k=k, dil=dil, last=int(bool(last)),
                             ld_dh=0 if d_h is None else _rows(d_h, "d_h"), ld_do=_rows(d_o, "d_o"), ldpre=_rows(pre, "pre"),
                             lddpre=_rows(d_pre, "d_pre"), ldout=_rows(d_h_out, "d_h_out"),
-                            d_h=None if last else p(d_h), d_o=d_o.data_ptr(), pre=pre.data_ptr(), w_rs_t=w_rs_t.data_ptr(),
-                            w_in_t=w_in_t.data_ptr(), d_pre=d_pre.data_ptr(), d_h_out=d_h_out.data_ptr(), lengths=p(lengths))
+                            d_h=None if last else p(d_h), d_o=d_o.data_ptr(), pre=pre.data_ptr(), w_rs_t=packed.ptr(layer, 2),
+                            w_in_t=packed.ptr(layer, 3), d_pre=d_pre.data_ptr(), d_h_out=d_h_out.data_ptr(), lengths=p(lengths))
     import ctypes
     e0 = _lib.timer.start("vits_wn_layer_bwd")
     rc = _lib.lib().vits_wn_layer_bwd(ctypes.addressof(d), _lib.stream_ptr())
@@ -455,8 +504,6 @@ def wn_layer_bwd(d_h, d_o, pre, w_rs_t, w_in_t, lengths, dil, last, d_pre, d_h_o
         _lib.timer.stop("vits_wn_layer_bwd", e0, (2.0 * b * t * H * (2 * H * k + c_rs),
                                                    es * (b * t * H * (6 + (0 if last else 1)) + (2 * k + c_rs // H) * H * H)),
                         shape=f"b{b} t{t} H{H} k{k} d{dil} last{int(bool(last))} {str(dt)[6:]}")
-    if rc == _lib.E_UNSUPPORTED:
-        return False
     _lib.check(rc, "vits_wn_layer_bwd")
     return True
 
@@ -724,3 +771,62 @@ def conv1d_cl_wgrad_raw(x, dy, k, lengths=None, dil=1, pad=0, stride=1, in_slope
                         shape=f"b{b} t{t} ci{c_in} co{c_out} k{k} d{dil} s{stride} {str(x.dtype)[6:]}")
     _lib.check(rc, "vits_conv1d_cl_wgrad")
     return out
+
+
+def conv1d_cl_wgrad_batch(entries, defer=None):
+    """The weight (+ bias) gradients of a group of stride-1 "same" convolutions in one launch per taps-per-group class
+    (vits_conv1d_cl_wgrad_batch, csrc/conv1d_wgrad_batch.hip).  entries: dicts with x [b,t,c_in], dy [b,t,c_out], k, out
+    (fp32 [k,c_out,c_in], written), and optionally dbias (fp32 [c_out]), lengths, dil, pad, flags.  With enough tiles in the
+    group nothing but `out` is written; a small group splits the reduction into slabs, which need `defer` (a
+    DeferredReductions collector: the caller flushes it).  Returns False when an entry is not eligible (nothing was launched)."""
+    import ctypes
+    L = _lib.lib()
+    n = len(entries)
+    descs = (_lib.WgradDesc * n)()
+    for d, e in zip(descs, entries):
+        x, dy, out = e["x"], e["dy"], e["out"]
+        _lib.require_cuda(x, dy, out)
+        b, t, c_in = x.shape
+        c_out, k = dy.shape[2], e["k"]
+        assert x.dtype == dy.dtype and tuple(dy.shape[:2]) == (b, t)
+        assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (k, c_out, c_in)
+        db, lengths = e.get("dbias"), e.get("lengths")
+        assert db is None or (db.dtype == torch.float32 and db.is_contiguous() and db.numel() == c_out)
+        d.dtype, d.b, d.t, d.c_in, d.c_out, d.k = _DT[x.dtype], b, t, c_in, c_out, k
+        d.dil, d.pad, d.stride, d.flags = e.get("dil", 1), e.get("pad", 0), 1, int(e.get("flags", 0))
+        d.ldx, d.lddy, d.in_slope, d.groups = _rows(x, "x"), _rows(dy, "dy"), 1.0, 1
+        d.x, d.dy, d.dw = x.data_ptr(), dy.data_ptr(), out.data_ptr()
+        d.lengths = None if lengths is None else lengths.data_ptr()
+        d.dbias = None if db is None else db.data_ptr()
+    # slabs only when the group is too small to fill the chip without splitting its reductions
+    pend = None
+    by_class = {}
+    for i, e in enumerate(entries):
+        by_class.setdefault(min(e["k"], 4) if e["k"] <= 4 else ((e["k"] + 1) // 2 if e["k"] <= 8 else 4), []).append(i)
+    if defer is not None:
+        for idxs in by_class.values():
+            grp = (_lib.WgradDesc * len(idxs))(*[descs[i] for i in idxs])
+            S = L.vits_conv1d_cl_wgrad_batch_splits(ctypes.addressof(grp), len(idxs))
+            if S > 1:
+                for i in idxs:
+                    d = descs[i]
+                    nbytes = S * (d.k * d.c_out * d.c_in + (d.c_out if d.dbias else 0)) * 4
+                    ws = defer.alloc(nbytes)
+                    if ws is not None:
+                        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+                pend = pend or (_lib.WgradPending * n)()
+    e0 = _lib.timer.start("vits_conv1d_cl_wgrad")
+    rc = L.vits_conv1d_cl_wgrad_batch(ctypes.addressof(descs), n, _lib.stream_ptr(), None if pend is None else ctypes.addressof(pend))
+    if rc == _lib.E_UNSUPPORTED:
+        return False
+    if e0 is not None:
+        es = entries[0]["x"].element_size()
+        fl = sum(2.0 * d.b * d.t * d.c_out * d.c_in * d.k for d in descs)
+        by = sum(es * d.b * d.t * (d.c_in + d.c_out) + 4.0 * d.k * d.c_out * d.c_in for d in descs)
+        _lib.timer.stop("vits_conv1d_cl_wgrad", e0, (fl, by), shape=f"batch of {n}: first b{descs[0].b} t{descs[0].t} ci{descs[0].c_in} co{descs[0].c_out} k{descs[0].k}")
+    _lib.check(rc, "vits_conv1d_cl_wgrad_batch")
+    if pend is not None:
+        for i in range(n):
+            if pend[i].splits > 0:
+                defer.add(pend[i])
+    return True

@@ -26,7 +26,7 @@ from .models import MultiPeriodDiscriminator, SynthesizerTrn
 
 
 class FineTuner:
-    def __init__(self, hps, device, amp=True, bucket_bytes=64 << 20, discriminator_seed=None):
+    def __init__(self, hps, device, amp=True, bucket_bytes=64 << 20, discriminator_seed=None, force_exchange=False):
         self.hps, self.device, self.amp = hps, torch.device(device), amp
         torch.manual_seed(hps.train.seed)                       # finetune_speaker_v2.py:70
         m = {k: v for k, v in hps.model.items()}
@@ -51,8 +51,8 @@ class FineTuner:
         # (34.5 -> 27.3 ms/step together; replays bitwise reproducible — DESIGN.md §6b tells how the "dp" branch exposed the
         # spline kernel's irreproducibility under concurrency and what cured it).  Also available, off: "mel" (slower).
         self.side_branches = frozenset(("enc_p", "dp"))
-        self.buckets_g = GradBuckets(self.net_g.parameters(), bucket_bytes)
-        self.buckets_d = GradBuckets(self.net_d.parameters(), bucket_bytes)
+        self.buckets_g = GradBuckets(self.net_g.parameters(), bucket_bytes, force=force_exchange)
+        self.buckets_d = GradBuckets(self.net_d.parameters(), bucket_bytes, force=force_exchange)
         self.sched_g = torch.optim.lr_scheduler.ExponentialLR(self.optim_g, gamma=hps.train.lr_decay)
         self.sched_d = torch.optim.lr_scheduler.ExponentialLR(self.optim_d, gamma=hps.train.lr_decay)
         self.net_g.train()
@@ -84,7 +84,7 @@ class FineTuner:
         seg_frames = hps.train.segment_size // hps.data.hop_length
         # side-stream branch of the duration predictor: not together with hook-mode bucket all-reduces (their packing copies
         # would run on whichever stream a gradient arrives on)
-        branches = self.side_branches if (self.buckets_g.world == 1 or self.buckets_g._manual) else frozenset()
+        branches = self.side_branches if (not self.buckets_g.active or self.buckets_g._manual) else frozenset()
         self.net_g.side_branches = branches
 
         with self._autocast():
@@ -278,6 +278,46 @@ class FineTuner:
             self._graph.replay()
         return self._static_out
 
+    # ---------------------------------------------------------------------------------------------
+    # Real batches change shape every step (bucketed by spectrogram length, finetune_speaker_v2.py:77 /
+    # data_utils.DistributedBucketSampler); a hipGraph has fixed shapes.  step_padded() pads a batch up to its
+    # bucket's shape — padding is inert: every layer masks by the lengths, the losses see slices and
+    # masked sums (tests/test_shape_policy_gpu.py: padded == unpadded, fp32) — and keeps ONE captured
+    # graph per padded shape: the first batch of a shape runs eagerly (and sizes the workspaces), the second
+    # captures, later ones only copy their data in and replay.  All graphs share one memory pool (they never
+    # run concurrently) and one capture stream (per-stream scratch is then shared too).
+    # ---------------------------------------------------------------------------------------------
+    def step_padded(self, batch, policy):
+        """One training iteration on `batch` padded to `policy`'s bucket shape; captured per shape from its second occurrence on.
+        Single-process form (data-parallel runs use capture_segments on one fixed shape)."""
+        padded = policy.pad(batch)
+        if self.device.type != "cuda" or self.buckets_g.active:
+            return self.step(padded)
+        key = tuple(tuple(t.shape) for t in padded)
+        cache = self.__dict__.setdefault("_shape_graphs", {})
+        ent = cache.get(key)
+        if ent is None:
+            cache[key] = {}
+            return self.step(padded)                              # eager: a real step, and the warm-up of this shape
+        if "graph" not in ent:
+            from . import _lib
+            timer_was, _lib.timer.enabled = _lib.timer.enabled, False
+            ent["batch"] = tuple(t.clone() for t in padded)
+            if "_capture_stream" not in self.__dict__:
+                self._capture_stream, self._graph_pool = torch.cuda.Stream(self.device), None
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, pool=self._graph_pool, stream=self._capture_stream):
+                ent["out"] = self.step(ent["batch"])
+            if self._graph_pool is None:
+                self._graph_pool = g.pool()
+            ent["graph"] = g
+            _lib.timer.enabled = timer_was
+        for dst, src in zip(ent["batch"], padded):
+            dst.copy_(src, non_blocking=True)
+        ent["graph"].replay()
+        return ent["out"]
+
     def epoch_end(self):
         self.sched_g.step()            # ExponentialLR per epoch, finetune_speaker_v2.py:157-158
         self.sched_d.step()
@@ -285,6 +325,31 @@ class FineTuner:
         # (a device fill outside the graph, stream-ordered before the next replay)
         self.optim_g._sync_lr()
         self.optim_d._sync_lr()
+
+
+class ShapePolicy:
+    """Pads a collated batch (x, x_lengths, spec, spec_lengths, y, y_lengths, speakers) to one of a few fixed shapes: the
+    spectrogram length up to the upper boundary of its sampler bucket (finetune_speaker_v2.py:77: [32, 300, 400, ..., 1000]),
+    the token length up to the next of `t_x_steps`.  Lengths are untouched, so the padding is masked everywhere."""
+
+    def __init__(self, boundaries, hop_length, t_x_steps=(128, 256, 384)):
+        self.boundaries, self.hop, self.t_x_steps = sorted(boundaries), hop_length, sorted(t_x_steps)
+
+    def padded_shape(self, t_x, t_y):
+        ty = next((b for b in self.boundaries if b >= t_y), t_y)
+        tx = next((s for s in self.t_x_steps if s >= t_x), t_x)
+        return tx, ty
+
+    def pad(self, batch):
+        x, x_lengths, spec, spec_lengths, y, y_lengths, speakers = batch
+        tx, ty = self.padded_shape(x.size(1), spec.size(2))
+        if tx != x.size(1):
+            x = F.pad(x, (0, tx - x.size(1)))
+        if ty != spec.size(2):
+            spec = F.pad(spec, (0, ty - spec.size(2)))
+        if y.size(2) != ty * self.hop:
+            y = F.pad(y, (0, ty * self.hop - y.size(2))) if y.size(2) < ty * self.hop else y[:, :, :ty * self.hop]
+        return (x, x_lengths, spec, spec_lengths, y, y_lengths, speakers)
 
 
 def evaluate(hps, generator, batch, max_len=1000):

@@ -137,6 +137,7 @@ class WNPlan:
         self.H, self.k, self.L = wn.hidden_channels, wn.kernel_size[0], wn.n_layers
         self.dils = [wn.dilation_rate ** i for i in range(self.L)]
         self.has_cond = wn.gin_channels != 0
+        self.packed = {}             # (dtype, device) -> kernels.WnPacked: the stack's operands in fragment order
 
 
 def wn_prepared_weights(wn):
@@ -182,18 +183,26 @@ class WNFn(torch.autograd.Function):
         cd = None if cond is None else cond.detach().float().contiguous()
         out = torch.empty_like(h)
         saved = []
-        fused = FUSED_LAYERS and lengths is not None
+        fused = FUSED_LAYERS and lengths is not None and K.wn_fusable(H, k, max(plan.dils), h.element_size())
+        packed = None
+        if fused:
+            # the stack's operands in MFMA-fragment order: one packing launch per forward (and, when a backward will follow, the
+            # data-gradient operands in the same launch)
+            packed = plan.packed.get((dtype, h.device))
+            if packed is None:
+                packed = plan.packed[(dtype, h.device)] = K.WnPacked(H, k, L, dtype, h.device)
+            need_bwd = any(ctx.needs_input_grad)       # (grad mode is off inside forward; this is what tells whether a backward can follow)
+            packed.fill([(R[4 * i].fwd, R[4 * i + 2].fwd) for i in range(L)],
+                        [(WA.bwd_operand(R[4 * i + 2]), WA.bwd_operand(R[4 * i])) for i in range(L)] if need_bwd else None)
         for i in range(L):
             r_in, b_in, r_rs, b_rs = R[4 * i], bias[4 * i + 1], R[4 * i + 2], bias[4 * i + 3]
             d = plan.dils[i]
             pre = torch.empty(h.size(0), h.size(1), 2 * H, device=h.device, dtype=dtype)
-            h_next = NotImplemented
             if fused:                                       # the whole layer as one launch (csrc/wn_layer.hip)
                 acts = torch.empty_like(h)
-                h_next = K.wn_layer_fwd(h, r_in.fwd, b_in, None if cd is None else cd[i], r_rs.fwd, b_rs, lengths, d, out,
+                h_next = K.wn_layer_fwd(h, packed, i, b_in, None if cd is None else cd[i], b_rs, lengths, d, out,
                                         accumulate=i > 0, last=i == L - 1, pre=pre, acts=acts)
-                fused = h_next is not NotImplemented
-            if h_next is NotImplemented:
+            else:
                 acts = C(h, r_in.fwd, b_in, bias_b=None if cd is None else cd[i], dil=d, pad=(k * d - d) // 2,
                          flags=K.CONV_GATE, gate_h=H, out2=pre)
                 acc = K.CONV_ACCUM if i > 0 else 0
@@ -206,7 +215,7 @@ class WNFn(torch.autograd.Function):
             saved += [h, pre, acts]
             h = h_next
         ctx.plan, ctx.dtype, ctx.lengths, ctx.has_cond, ctx.R = plan, dtype, lengths, cd is not None, R
-        ctx.fused = fused
+        ctx.fused, ctx.packed = fused, packed
         ctx.save_for_backward(*saved)
         return out
 
@@ -255,40 +264,50 @@ class WNFn(torch.autograd.Function):
     @staticmethod
     def _backward_fused(ctx, dcat, saved, grads, defer):
         """One data-gradient launch per layer (vits_wn_layer_bwd: the 1x1 data gradient, the gate's chain rule and the k-tap data
-        gradient with its residual path) between two [d_h | d_o] buffers, both holding d_o in their right halves: a layer
-        reads one and writes its d_h into the other's left half, so neighbouring time tiles never see a half-updated row.
-        The weight gradients follow each layer's launch (stream order protects the buffer they read); the gradient of the
-        conditioning is ONE per-item column sum over all layers' d_pre at the end."""
+        gradient with its residual path); every layer writes its d_h into a buffer of its own, so neighbouring time tiles
+        never see a half-updated row and the weight gradients can wait: ALL of the stack's weight / bias gradients are then
+        one batched launch per taps-per-group class (vits_conv1d_cl_wgrad_batch: no per-split slabs when the stack has enough
+        tiles), and the gradient of the conditioning is ONE per-item column sum over all layers' d_pre."""
         plan, lengths, R = ctx.plan, ctx.lengths, ctx.R
         WG = K.conv1d_cl_wgrad_raw
         H, L, k = plan.H, plan.L, plan.k
         b, t = dcat.size(0), dcat.size(1)
         dev, dtype = dcat.device, dcat.dtype
-        bufs = [dcat, torch.empty_like(dcat)]
-        bufs[1][..., H:].copy_(dcat[..., H:])
         d_pre_all = torch.empty(L, b, t, 2 * H, device=dev, dtype=dtype)
-        cur = 0
+        # every layer keeps its own d_h (the res half of its res_skip weight gradient reads it after the loop)
+        dh_all = torch.empty(max(L - 1, 1), b, t, H, device=dev, dtype=dtype)
+        d_o = dcat[..., H:]
+        batch, d_h = [], None
         for i in reversed(range(L)):
             acts, pre, h = saved.pop(), saved.pop(), saved.pop()
             r_in, r_rs = R[4 * i], R[4 * i + 2]
             d = plan.dils[i]
             pad = (k * d - d) // 2
             last = i == L - 1
-            src, dst = bufs[cur], bufs[1 - cur]
-            ok = K.wn_layer_bwd(None if last else src[..., :H], src[..., H:], pre, WA.bwd_operand(r_rs), WA.bwd_operand(r_in), lengths, d, last,
-                                d_pre_all[i], dst[..., :H])
-            if not ok:
-                raise RuntimeError("vits_wn_layer_bwd refused a shape vits_wn_layer_fwd accepted")
+            dst = dh_all[i - 1] if i > 0 else torch.empty(b, t, H, device=dev, dtype=dtype)
+            K.wn_layer_bwd(d_h, d_o, pre, ctx.packed, i, lengths, d, last, d_pre_all[i], dst)
+            # weight gradients: collected, launched together below (the layers of the stack are each other's parallelism)
+            dw_rs, dw_in = r_rs.claim_dw(ctx), r_in.claim_dw(ctx)
+            if dw_rs is None:
+                dw_rs = torch.empty(1, H if last else 2 * H, H, device=dev, dtype=torch.float32)
+            if dw_in is None:
+                dw_in = torch.empty(k, 2 * H, H, device=dev, dtype=torch.float32)
             db_rs = torch.empty(H if last else 2 * H, dtype=torch.float32, device=dev)
-            grads[4 * i + 2] = WG(acts, src[..., H:] if last else src, 1, out=r_rs.claim_dw(ctx), dbias=db_rs, defer=defer)
-            grads[4 * i + 3] = db_rs
             db_in = torch.empty(2 * H, dtype=torch.float32, device=dev)
-            grads[4 * i] = WG(h, d_pre_all[i], k, dil=d, pad=pad, out=r_in.claim_dw(ctx), dbias=db_in, defer=defer)
-            grads[4 * i + 1] = db_in
-            cur = 1 - cur
+            if last:
+                batch.append(dict(x=acts, dy=d_o, k=1, out=dw_rs, dbias=db_rs))
+            else:                                                   # rows [0, H) of W_rs see d_h, rows [H, 2H) see d_o
+                batch.append(dict(x=acts, dy=d_h, k=1, out=dw_rs[:, :H], dbias=db_rs[:H]))
+                batch.append(dict(x=acts, dy=d_o, k=1, out=dw_rs[:, H:], dbias=db_rs[H:]))
+            batch.append(dict(x=h, dy=d_pre_all[i], k=k, dil=d, pad=pad, out=dw_in, dbias=db_in))
+            grads[4 * i + 2], grads[4 * i + 3], grads[4 * i], grads[4 * i + 1] = dw_rs, db_rs, dw_in, db_in
+            d_h = dst
+        if not K.conv1d_cl_wgrad_batch(batch, defer):
+            for e in batch:                                         # (not eligible: one launch per convolution)
+                WG(e["x"], e["dy"], e["k"], dil=e.get("dil", 1), pad=e.get("pad", 0), out=e["out"], dbias=e["dbias"], defer=defer)
         defer.flush()
         dc = K.colsum(d_pre_all.view(L * b, t, 2 * H), per_item=True).view(L, b, 2 * H) if ctx.has_cond else None
-        return (None, None, bufs[cur][..., :H].contiguous(), None, dc, *grads)
+        return (None, None, d_h, None, dc, *grads)
 
 
 def wn_forward_cl(wn, x_cl, lengths, g):

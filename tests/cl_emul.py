@@ -344,9 +344,20 @@ def dequant_log(zq, w, lengths):
     return torch.cat([z0, z1], -1), s1, torch.sum(-z0, [1, 2])
 
 
-def wn_layer_fwd(x, w_in, b_in, cond, w_rs, b_rs, lengths, dil, skip, accumulate, last, pre=None, acts=None):
+class WnPacked:
+    """stand-in of kernels.WnPacked: keeps the row-major operands (the emulation has no fragment order)"""
+
+    def __init__(self, H, k, L, dtype, device):
+        self.H, self.k, self.L, self.dtype, self.with_bwd = H, k, L, dtype, False
+
+    def fill(self, fwd_ops, bwd_ops):
+        self.fwd_ops, self.bwd_ops, self.with_bwd = fwd_ops, bwd_ops, bwd_ops is not None
+
+
+def wn_layer_fwd(x, packed, layer, b_in, cond, b_rs, lengths, dil, skip, accumulate, last, pre=None, acts=None):
     """vits_wn_layer_fwd (include/vitsmi.h): gate convolution + tanh*sigmoid + 1x1 res/skip + residual / skip epilogues."""
     b, t, H = x.shape
+    w_in, w_rs = packed.fwd_ops[layer]
     k = w_in.size(0)
     v = F.conv1d(x.float().transpose(1, 2), w_in.float().permute(1, 2, 0), None, 1, (k - 1) * dil // 2, dil).transpose(1, 2)
     if b_in is not None:
@@ -368,9 +379,10 @@ def wn_layer_fwd(x, w_in, b_in, cond, w_rs, b_rs, lengths, dil, skip, accumulate
     return None if last else ((x.float() + rs[..., :H]) * m).to(x.dtype)
 
 
-def wn_layer_bwd(d_h, d_o, pre, w_rs_t, w_in_t, lengths, dil, last, d_pre, d_h_out):
+def wn_layer_bwd(d_h, d_o, pre, packed, layer, lengths, dil, last, d_pre, d_h_out):
     """vits_wn_layer_bwd (include/vitsmi.h) on the data-gradient operands: w_rs_t [1][H][2H|H], w_in_t [k][H][2H] (tap-reversed)."""
     b, t, H = d_o.shape
+    w_rs_t, w_in_t = packed.bwd_ops[layer]
     k = w_in_t.size(0)
     m = (torch.arange(t, device=d_o.device)[None, :, None] < lengths[:, None, None])
     dcat = d_o.float() if last else torch.cat([d_h.float(), d_o.float()], -1)
@@ -386,9 +398,19 @@ def wn_layer_bwd(d_h, d_o, pre, w_rs_t, w_in_t, lengths, dil, last, d_pre, d_h_o
     return True
 
 
+def conv1d_cl_wgrad_batch(entries, defer=None):
+    """vits_conv1d_cl_wgrad_batch: every entry is an ordinary weight (+ bias) gradient."""
+    for e in entries:
+        conv1d_cl_wgrad_raw(e["x"], e["dy"], e["k"], lengths=e.get("lengths"), dil=e.get("dil", 1), pad=e.get("pad", 0),
+                            flags=e.get("flags", 0), out=e["out"], dbias=e.get("dbias"))
+    return True
+
+
 def install_rowops(monkeypatch):
     import importlib
+    monkeypatch.setattr(importlib.import_module("personalized_text-to-speech_amd.kernels"), "conv1d_cl_wgrad_batch", conv1d_cl_wgrad_batch)
     monkeypatch.setattr(importlib.import_module("personalized_text-to-speech_amd.kernels"), "wn_layer_fwd", wn_layer_fwd)
+    monkeypatch.setattr(importlib.import_module("personalized_text-to-speech_amd.kernels"), "WnPacked", WnPacked)
     monkeypatch.setattr(importlib.import_module("personalized_text-to-speech_amd.kernels"), "wn_layer_bwd", wn_layer_bwd)
     R = importlib.import_module("personalized_text-to-speech_amd.rowops")
     monkeypatch.setattr(R, "ln_act", ln_act)

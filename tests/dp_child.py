@@ -25,8 +25,8 @@ def tiny_hps(cfgs, cfg):
                              model=dict(cfg["model"], use_spectral_norm=False), n_symbols=cfg["n_vocab"]))
 
 
-def make_tuner(P, cfgs, tr, g, cfg):
-    ft = tr.FineTuner(tiny_hps(cfgs, cfg), "cuda:0", amp=False, discriminator_seed=cfg["d_seed"])
+def make_tuner(P, cfgs, tr, g, cfg, force_exchange=False):
+    ft = tr.FineTuner(tiny_hps(cfgs, cfg), "cuda:0", amp=False, discriminator_seed=cfg["d_seed"], force_exchange=force_exchange)
     ft.net_g.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd/")}, strict=True)
     ft.net_g.eval(); ft.net_d.eval()
     return ft
@@ -60,15 +60,18 @@ def dump(path, ft, losses):
 
 def main():
     rank, world, port, path, mode = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    backend = os.environ.get("VITS_DIST_BACKEND", "gloo")          # "nccl" (= RCCL): one rank per GPU, so world must be 1 on the test box
+    if backend == "nccl":
+        torch.cuda.set_device(0)
+    dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     from importlib import import_module
     P = import_module("personalized_text-to-speech_amd")
     cfgs = import_module("personalized_text-to-speech_amd.configs")
     tr = import_module("personalized_text-to-speech_amd.train")
     g = np.load(os.path.join(ROOT, "tests", "golden", "step_tiny.npz"))
     cfg = json.loads(bytes(g["config"]).decode())
-    ft = make_tuner(P, cfgs, tr, g, cfg)
-    assert ft.buckets_g.world == world and len(ft.buckets_g.buckets) > 0
+    ft = make_tuner(P, cfgs, tr, g, cfg, force_exchange=world == 1)
+    assert ft.buckets_g.world == world and len(ft.buckets_g.buckets) > 0 and dist.get_backend() == backend
     batch = make_batch(P, cfg, rank)
     losses = []
     keys = ("loss_disc", "loss_gen", "loss_fm", "loss_mel", "loss_dur", "loss_kl", "grad_norm_d", "grad_norm_g")

@@ -198,6 +198,7 @@ def test_lr_decay_reaches_the_replayed_graph(pkg):
     with torch.no_grad():
         for t, s in zip(ts, snap):
             t.copy_(s)
+    ft.optim_g._sync_lr(force=True); ft.optim_d._sync_lr(force=True)     # (the snapshot also restored the device copy of the OLD rate)
     torch.cuda.set_rng_state(rng, ft.device)
     ft.step(batch); torch.cuda.synchronize()
     g2 = ft.optim_g.flat_p - snap[0]

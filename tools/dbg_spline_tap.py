@@ -79,8 +79,22 @@ def within(cur, tag):
             continue
         for a, b in (("gh", "gh_again"), ("dx2", "dx2_again")) + tuple((k + "_before", k + "_after") for k in ("x2", "h", "mask", "dy2", "dlogdet")):
             if not torch.equal(rec[a], rec[b]):
-                n = int((rec[a].float() != rec[b].float()).sum())
-                print(f"   WITHIN {tag} call {ci}: {a} != {b} in {n} elements", flush=True)
+                A, B = rec[a].float(), rec[b].float()
+                idx = (A != B).nonzero()
+                print(f"   WITHIN {tag} call {ci}: {a} != {b} in {idx.size(0)} elements", flush=True)
+                if a == "gh":
+                    A2, B2 = A.reshape(-1, A.size(-1)), B.reshape(-1, B.size(-1))
+                    rows = sorted({int(i[0]) * A.size(1) + int(i[1]) for i in idx.tolist()})
+                    print(f"      flat rows {rows[0]}..{rows[-1]} ({len(rows)}); lanes {rows[0] % 64}..{rows[-1] % 64}; channels {sorted({int(i[2]) for i in idx.tolist()})}")
+                    for rr in rows[:3]:
+                        print(f"      row {rr} first : {[f'{v:.4e}' for v in A2[rr].tolist()]}")
+                        print(f"      row {rr} second: {[f'{v:.4e}' for v in B2[rr].tolist()]}")
+                        ch = [int(i[2]) for i in idx.tolist() if int(i[0]) * A.size(1) + int(i[1]) == rr]
+                        for cc in ch[:2]:
+                            for nm, X, Y in (("first", A2, B2), ("second", B2, A2)):
+                                same_row = [j for j in range(X.size(1)) if X[rr, j] == Y[rr, cc] and j != cc]
+                                other_rows = (X[:, cc] == Y[rr, cc]).nonzero().flatten().tolist()[:6]
+                                print(f"         value of the {('second','first')[nm=='second']} run at channel {cc} also found in the {nm} run: same row channels {same_row}, same channel rows {other_rows}")
 
 
 NR = int(os.environ.get("NREP", "30"))
