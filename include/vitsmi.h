@@ -111,6 +111,10 @@ int vits_mas_f32(const float* neg_cent, void* path, int path_dtype,
 #define VITS_CONV_BIG_TILES 512 /* vits_conv1d_cl_wgrad only: take the 128 x 128-tile kernel wherever it can run (by default only
                                    where it is the faster one: stride 1, >= 512 channels on both sides) */
 #define VITS_CONV_OUT_LRELU 128 /* y = leaky_relu(., out_slope) applied after residual/scale (discriminator feature maps) */
+#define VITS_CONV_RES_SKIP 1024 /* the res_skip layer of a WaveNet layer in one launch (modules.py:166-174): c_out = 2*gate_h; columns
+                                   [0, gate_h): y = (conv + bias + res) * mask (y, res: gate_h columns, pitch ldy); columns [gate_h, 2*gate_h):
+                                   y2 (+)= (conv + bias) * mask (gate_h columns, pitch ldy2; VITS_CONV_ACCUM applies to y2 only).
+                                   Needs lengths (the mask) and y2; tiled kernel only. */
 
 /* All sizes in elements.  Zero in ldx / ldy / ldy2 / stride means "dense" / 1. */
 typedef struct vits_conv_desc {

@@ -333,6 +333,36 @@ __global__ __launch_bounds__(kThreads) void conv1d_cl_kernel(ConvArgs args) {
     return;
   }
 
+  if (a.flags & VITS_CONV_RES_SKIP) {
+    // WaveNet res_skip layer: the first gate_h columns are the residual update, the rest is added into the skip sum (y2)
+    T* Y2 = static_cast<T*>(a.y2) + (size_t)b * Tout * a.ldy2;
+    const bool accum = (a.flags & VITS_CONV_ACCUM) != 0;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int co = co0 + (wn * NT + n) * 32 + r;
+      if (co >= a.c_out) continue;
+      const float bsum = a.bias ? a.bias[co] : 0.f;
+      const bool is_res = co < a.gate_h;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int t = t0 + wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (t >= Tout) continue;
+        float v = acc[n][i] + bsum;
+        if (is_res) {
+          const size_t o = (size_t)t * a.ldy + co;
+          v += to_f(R[o]);
+          Y[o] = from_f<T>(t < len ? v : 0.f);
+        } else {
+          const size_t o = (size_t)t * a.ldy2 + (co - a.gate_h);
+          v = t < len ? v : 0.f;
+          if (accum) v += to_f(Y2[o]);
+          Y2[o] = from_f<T>(v);
+        }
+      }
+    }
+    return;
+  }
+
   // the common epilogue (bias, scale, output leaky-relu, output mask: no memory operand besides the bias) without a flag test
   // per element — most of the step's ~400 small launches end here, and the generic loop below spends a branch per flag per element
   if (!R && !MG && !a.bias_b && !(a.flags & (VITS_CONV_ACCUM | VITS_CONV_TANH | VITS_CONV_GATE_BWD))) {
@@ -504,11 +534,13 @@ extern "C" int vits_conv1d_cl(const vits_conv_desc* desc, void* stream) {
   const bool gate = (d.flags & VITS_CONV_GATE) != 0, gate_bwd = (d.flags & VITS_CONV_GATE_BWD) != 0;
   if (gate && (d.gate_h <= 0 || d.c_out != 2 * d.gate_h)) return VITS_E_BADARG;
   if (gate_bwd && (d.gate_h != d.c_out || !d.mg_src)) return VITS_E_BADARG;
+  const bool res_skip = (d.flags & VITS_CONV_RES_SKIP) != 0;
+  if (res_skip && (d.gate_h <= 0 || d.c_out != 2 * d.gate_h || !d.y2 || !d.res || !d.lengths || gate || gate_bwd || d.mg_src || d.bias_b)) return VITS_E_BADARG;
   if (d.ldx <= 0) d.ldx = d.c_in;
   if (d.ldw <= 0) d.ldw = d.c_in;
   if (d.w_batch_stride < 0) return VITS_E_BADARG;
-  if (d.ldy <= 0) d.ldy = gate ? d.gate_h : (gate_bwd ? 2 * d.gate_h : d.c_out);
-  if (d.ldy2 <= 0) d.ldy2 = d.c_out;
+  if (d.ldy <= 0) d.ldy = (gate || res_skip) ? d.gate_h : (gate_bwd ? 2 * d.gate_h : d.c_out);
+  if (d.ldy2 <= 0) d.ldy2 = res_skip ? d.gate_h : d.c_out;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int vec = d.dtype == VITS_DT_BF16 ? 8 : (d.dtype == VITS_DT_F32 ? 4 : 0);
   if (vec == 0) return VITS_E_UNSUPPORTED;
@@ -520,7 +552,7 @@ extern "C" int vits_conv1d_cl(const vits_conv_desc* desc, void* stream) {
   }
   // flat-row kernel: strided / divided launches, and short sequences spread over many items (most of a per-item
   // time tile would be empty).  It has no gate epilogues and no per-item operands.
-  const bool flat_ok = !gate && !gate_bwd && d.w_batch_stride == 0 && d.y2 == nullptr;
+  const bool flat_ok = !gate && !gate_bwd && !res_skip && d.w_batch_stride == 0 && d.y2 == nullptr;
   if (d.groups > 1 && (d.c_out % d.groups != 0 || d.c_in % d.groups != 0)) return VITS_E_BADARG;
   const bool must_flat = in_div > 1 || (d.flags & VITS_CONV_FLAT) != 0 || d.groups > 1;
   if (must_flat && !flat_ok) return VITS_E_UNSUPPORTED;

@@ -268,9 +268,19 @@ __global__ void spline_kernel(const float* __restrict__ x, const TH* __restrict_
   knots_bwd(kh, i, g_CH - g_H, g_H, B, g_uh);
   gx[ix] = g_x;
   if (FLOW) gx[ip] = gy[ip] * mv;
+#ifdef VITS_SPLINE_VOLATILE_STORE
+  volatile TH* gr = gh + (size_t)e * ldh;
+#else
   TH* gr = gh + (size_t)e * ldh;
+#endif
+#ifdef VITS_SPLINE_STORE_NOPS
+  asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+#endif
 #pragma unroll
   for (int j = 0; j < NB; ++j) { gr[j] = from_f<TH>(g_uw[j] * hscale); gr[NB + j] = from_f<TH>(g_uh[j] * hscale); }
+#ifdef VITS_SPLINE_STORE_NOPS
+  asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+#endif
 #pragma unroll
   for (int j = 0; j < NB - 1; ++j) {
     float g = 0.f;

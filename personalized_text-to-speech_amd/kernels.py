@@ -319,6 +319,7 @@ def stft_mel(y, n_fft, hop, win, window, basis, clip=1e-5):
 CONV_MASK_IN, CONV_MASK_OUT, CONV_TANH, CONV_ACCUM, CONV_RES_AFTER, CONV_GATE, CONV_GATE_BWD, CONV_OUT_LRELU = 1, 2, 4, 8, 16, 32, 64, 128
 CONV_FLAT = 256
 CONV_BIG_TILES = 512
+CONV_RES_SKIP = 1024
 _DT = {torch.float32: 0, torch.bfloat16: 2}
 
 
@@ -350,9 +351,11 @@ def conv1d_cl_raw(x, w, bias=None, bias_b=None, res=None, mg_src=None, out=None,
         assert stride == 1 and t_out is not None
     else:
         t_out = (t + 2 * pad - dil * (k - 1) - 1) // stride + 1
-    y_cols = gate_h if (flags & CONV_GATE) else (2 * gate_h if (flags & CONV_GATE_BWD) else c_out)
+    y_cols = gate_h if (flags & (CONV_GATE | CONV_RES_SKIP)) else (2 * gate_h if (flags & CONV_GATE_BWD) else c_out)
+    if flags & CONV_RES_SKIP:               # res half -> y (+ res), skip half (+)= into out2; ACCUM is about out2
+        assert c_out == 2 * gate_h and out2 is not None and tuple(out2.shape) == (b, t_out, gate_h) and res is not None and lengths is not None
     if out is None:
-        assert not (flags & CONV_ACCUM)
+        assert not (flags & CONV_ACCUM) or (flags & CONV_RES_SKIP)
         out = torch.empty((b, t_out, y_cols), device=x.device, dtype=x.dtype)
     assert out.dtype == x.dtype and tuple(out.shape) == (b, t_out, y_cols)
     ldy = _rows(out, "out")

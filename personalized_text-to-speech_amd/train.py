@@ -155,10 +155,11 @@ class FineTuner:
     # CPU-launch-bound in eager mode; once shapes are fixed (one length bucket) the whole iteration —
     # both forwards, both backwards, both AdamW updates — is captured once and replayed.
     # ---------------------------------------------------------------------------------------------
-    def capture(self, batch, warmup=3):
-        """Warm up (MIOpen solver selection, workspace growth, optimizer state) on a side stream,
-        then capture one step on `batch`'s storage.  Afterwards `replay()` runs one iteration on
-        whatever has been copied into those tensors."""
+    def capture(self, batch, warmup=3, verify=True):
+        """Warm up (workspace growth, optimizer state) on a side stream, then capture one step on `batch`'s storage.  Afterwards
+        `replay()` runs one iteration on whatever has been copied into those tensors.  verify: run verify_replay() once before
+        returning (two replays and one eager step from the same state must agree; state is restored) — a captured graph whose
+        side-stream branches race, or that depends on memory a replay does not re-initialise, never reaches training."""
         from . import _lib
         assert self.device.type == "cuda" and self._graph is None
         timer_was, _lib.timer.enabled = _lib.timer.enabled, False
@@ -174,9 +175,11 @@ class FineTuner:
         with torch.cuda.graph(self._graph):
             self._static_out = self.step(batch)
         _lib.timer.enabled = timer_was
+        if verify:
+            self.verify_replay()
         return self._static_out
 
-    def capture_segments(self, batch, warmup=3):
+    def capture_segments(self, batch, warmup=3, verify=True):
         """Data-parallel form of capture(): the step as THREE graphs sharing one memory pool, cut at the two points where
         ranks exchange gradients.  Each graph ends by packing its network's gradients into the flat buckets; the bucket
         all-reduces run eagerly between the replays (RCCL is not captured), then the next graph reads the reduced
@@ -206,6 +209,8 @@ class FineTuner:
             self._static_out = self._phase_c()
         self._graph = (ga, gb, gc)
         _lib.timer.enabled = timer_was
+        if verify:                                   # (collectives inside: every rank captures, so every rank verifies)
+            self.verify_replay()
         return self._static_out
 
     def _state_tensors(self):
@@ -293,21 +298,31 @@ class FineTuner:
         padded = policy.pad(batch)
         if self.device.type != "cuda" or self.buckets_g.active:
             return self.step(padded)
+        # Everything — the eager first step of a shape too — runs on ONE non-default stream: autograd keeps the stream of the
+        # step that created a parameter's AccumulateGrad node, and a capture that has to synchronise with the legacy default
+        # stream is illegal (hipStreamEndCapture crashes on it; FineTuner.capture warms up on a side stream for the same reason).
+        if "_capture_stream" not in self.__dict__:
+            self._capture_stream, self._graph_pool = torch.cuda.Stream(self.device), None
+        cs, cur = self._capture_stream, torch.cuda.current_stream(self.device)
         key = tuple(tuple(t.shape) for t in padded)
         cache = self.__dict__.setdefault("_shape_graphs", {})
         ent = cache.get(key)
         if ent is None:
             cache[key] = {}
-            return self.step(padded)                              # eager: a real step, and the warm-up of this shape
+            cs.wait_stream(cur)
+            with torch.cuda.stream(cs):
+                out = self.step(padded)                           # eager: a real step, and the warm-up of this shape
+            for t in padded:
+                t.record_stream(cs)
+            cur.wait_stream(cs)
+            return out
         if "graph" not in ent:
             from . import _lib
             timer_was, _lib.timer.enabled = _lib.timer.enabled, False
             ent["batch"] = tuple(t.clone() for t in padded)
-            if "_capture_stream" not in self.__dict__:
-                self._capture_stream, self._graph_pool = torch.cuda.Stream(self.device), None
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
-            with torch.cuda.graph(g, pool=self._graph_pool, stream=self._capture_stream):
+            with torch.cuda.graph(g, pool=self._graph_pool, stream=cs):
                 ent["out"] = self.step(ent["batch"])
             if self._graph_pool is None:
                 self._graph_pool = g.pool()

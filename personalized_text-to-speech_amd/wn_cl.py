@@ -167,7 +167,14 @@ def wn_cond(wn, g, n_items):
     return c.view(n_items, wn.n_layers, 2 * wn.hidden_channels).transpose(0, 1).contiguous()
 
 
-FUSED_LAYERS = True          # one launch per WaveNet layer and direction (csrc/wn_layer.hip); False = the three-launch composition
+# True: one launch per WaveNet layer and direction (csrc/wn_layer.hip: gate convolution + gate + res/skip product with the gate
+# tile in LDS; its mirror image for the data gradients).  Measured on the step's shape (b 16, t 500, H 192; tools/ubench_wn.py,
+# profiles/r03_pmc_wn.txt): 38 us forward / 45 us backward per layer against 2 x ~10.8 us / 2 x ~10.8 us for the composition below
+# inside the captured step — one wave per SIMD (152 KB of LDS, 223 + 96 registers) leaves the layer's ~6 k vector instructions of
+# gate / epilogue arithmetic and its waits with nothing to overlap with, while the composition's launches run 1.5-3 workgroups
+# per CU.  So the composition stays the default; the fused kernels are kept tested (tests/test_wn_layer_gpu.py) as the starting
+# point for a two-waves-per-SIMD version.
+FUSED_LAYERS = False
 
 
 class WNFn(torch.autograd.Function):
@@ -206,9 +213,8 @@ class WNFn(torch.autograd.Function):
                 acts = C(h, r_in.fwd, b_in, bias_b=None if cd is None else cd[i], dil=d, pad=(k * d - d) // 2,
                          flags=K.CONV_GATE, gate_h=H, out2=pre)
                 acc = K.CONV_ACCUM if i > 0 else 0
-                if i < L - 1:                               # rows [0, H) of the res_skip operand feed the residual, [H, 2H) the skip sum
-                    h_next = C(acts, r_rs.fwd[:, :H], b_rs[:H], res=h, lengths=lengths, flags=K.CONV_MASK_OUT)
-                    C(acts, r_rs.fwd[:, H:], b_rs[H:], out=out, lengths=lengths, flags=K.CONV_MASK_OUT | acc)
+                if i < L - 1:                               # rows [0, H) of the res_skip operand feed the residual, [H, 2H) the skip sum:
+                    h_next = C(acts, r_rs.fwd, b_rs, res=h, lengths=lengths, flags=K.CONV_RES_SKIP | acc, gate_h=H, out2=out)   # one launch
                 else:
                     h_next = None
                     C(acts, r_rs.fwd, b_rs, out=out, lengths=lengths, flags=K.CONV_MASK_OUT | acc)
@@ -221,45 +227,54 @@ class WNFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_out):
-        """Per layer: ONE weight-gradient launch for the res_skip convolution (dy = [d_h | d_o], a [b,t,2H] buffer whose
-        left half is rewritten in place by each layer's data gradient), ONE data-gradient launch through it (reduction
-        over 2H channels, gate chain rule as epilogue), the in-layer weight gradient with its bias gradient in the same
-        launch, and the in-layer data gradient accumulated onto d_h in place."""
+        """Per layer TWO data-gradient launches — through the res_skip convolution with the gate's chain rule as epilogue (reduction
+        over 2H channels of the layer's own [d_h | d_o] buffer), and through the in-layer convolution with the residual path, written
+        into the next layer's buffer — and then ALL weight / bias gradients of the stack as one batched launch per taps-per-group
+        class (vits_conv1d_cl_wgrad_batch) plus ONE per-item column sum for the gradient of the conditioning."""
         plan, dtype, lengths, R = ctx.plan, ctx.dtype, ctx.lengths, ctx.R
         C, WG = K.conv1d_cl_raw, K.conv1d_cl_wgrad_raw
         H, L, k = plan.H, plan.L, plan.k
         saved = list(ctx.saved_tensors)
         grads = [None] * len(R)
         b, t = d_out.size(0), d_out.size(1)
-        rowmask = (torch.arange(t, device=d_out.device)[None, :, None] < lengths[:, None, None])
-        dcat = torch.empty(b, t, 2 * H, device=d_out.device, dtype=dtype)
-        torch.mul(d_out, rowmask, out=dcat[..., H:]) if d_out.dtype == dtype else dcat[..., H:].copy_(d_out * rowmask)   # d(output * x_mask)
-        d_h, d_o = dcat[..., :H], dcat[..., H:]
-        dcond = [] if ctx.has_cond else None
-        defer = K.DeferredReductions(d_out.device)      # the 2L slab reductions of this stack run as one launch at the end
+        dev = d_out.device
+        rowmask = (torch.arange(t, device=dev)[None, :, None] < lengths[:, None, None])
+        # layer i reads dcat_all[i] = [d_h_i | d_o] (d_o = d(output * x_mask), the same for every layer: one broadcast copy)
+        dcat_all = torch.empty(L, b, t, 2 * H, device=dev, dtype=dtype)
+        dcat_all[..., H:] = (d_out * rowmask).to(dtype).unsqueeze(0)
+        defer = K.DeferredReductions(dev)               # slab reductions of a small stack: one launch at the end
         if ctx.fused:
-            return WNFn._backward_fused(ctx, dcat, saved, grads, defer)
+            return WNFn._backward_fused(ctx, dcat_all[L - 1], saved, grads, defer)
+        d_pre_all = torch.empty(L, b, t, 2 * H, device=dev, dtype=dtype)
+        dx_buf = torch.empty(b, t, 2 * H, device=dev, dtype=dtype)
+        batch = []
         for i in reversed(range(L)):
             acts, pre, h = saved.pop(), saved.pop(), saved.pop()
             r_in, r_rs = R[4 * i], R[4 * i + 2]
             d = plan.dils[i]
             pad = (k * d - d) // 2
             last = i == L - 1
-            dy_rs = d_o if last else dcat
-            db_rs = torch.empty(H if last else 2 * H, dtype=torch.float32, device=d_out.device)
-            grads[4 * i + 2] = WG(acts, dy_rs, 1, out=r_rs.claim_dw(ctx), dbias=db_rs, defer=defer)
-            grads[4 * i + 3] = db_rs
-            d_pre = C(dy_rs, WA.bwd_operand(r_rs), None, mg_src=pre, lengths=lengths, flags=K.CONV_GATE_BWD | K.CONV_MASK_OUT, gate_h=H)
-            db_in = torch.empty(2 * H, dtype=torch.float32, device=d_out.device)
-            grads[4 * i] = WG(h, d_pre, k, dil=d, pad=pad, out=r_in.claim_dw(ctx), dbias=db_in, defer=defer)
-            grads[4 * i + 1] = db_in
-            if dcond is not None:
-                dcond.append(K.colsum(d_pre, per_item=True))              # [b, 2H]: gradient of cond[i]
-            C(d_pre, WA.bwd_operand(r_in), None, res=None if last else d_h, out=d_h, lengths=lengths, dil=d, pad=pad,
+            dy_rs = dcat_all[i][..., H:] if last else dcat_all[i]
+            C(dy_rs, WA.bwd_operand(r_rs), None, mg_src=pre, out=d_pre_all[i], lengths=lengths, flags=K.CONV_GATE_BWD | K.CONV_MASK_OUT, gate_h=H)
+            dst = (dcat_all[i - 1] if i > 0 else dx_buf)[..., :H]
+            C(d_pre_all[i], WA.bwd_operand(r_in), None, res=None if last else dcat_all[i][..., :H], out=dst, lengths=lengths, dil=d, pad=pad,
               flags=K.CONV_MASK_OUT | (0 if last else K.CONV_RES_AFTER))
+            dw_rs, dw_in = r_rs.claim_dw(ctx), r_in.claim_dw(ctx)
+            if dw_rs is None:
+                dw_rs = torch.empty(1, H if last else 2 * H, H, device=dev, dtype=torch.float32)
+            if dw_in is None:
+                dw_in = torch.empty(k, 2 * H, H, device=dev, dtype=torch.float32)
+            db_rs = torch.empty(H if last else 2 * H, dtype=torch.float32, device=dev)
+            db_in = torch.empty(2 * H, dtype=torch.float32, device=dev)
+            batch.append(dict(x=acts, dy=dy_rs, k=1, out=dw_rs, dbias=db_rs))
+            batch.append(dict(x=h, dy=d_pre_all[i], k=k, dil=d, pad=pad, out=dw_in, dbias=db_in))
+            grads[4 * i + 2], grads[4 * i + 3], grads[4 * i], grads[4 * i + 1] = dw_rs, db_rs, dw_in, db_in
+        if not K.conv1d_cl_wgrad_batch(batch, defer):
+            for e in batch:                                         # (not eligible: one launch per convolution)
+                WG(e["x"], e["dy"], e["k"], dil=e.get("dil", 1), pad=e.get("pad", 0), out=e["out"], dbias=e["dbias"], defer=defer)
         defer.flush()
-        dc = torch.stack(dcond[::-1], 0) if dcond is not None else None
-        return (None, None, d_h.contiguous(), None, dc, *grads)
+        dc = K.colsum(d_pre_all.view(L * b, t, 2 * H), per_item=True).view(L, b, 2 * H) if ctx.has_cond else None
+        return (None, None, dx_buf[..., :H].contiguous(), None, dc, *grads)
 
     @staticmethod
     def _backward_fused(ctx, dcat, saved, grads, defer):

@@ -20,7 +20,7 @@ def conv1d_cl_raw(x, w, bias=None, bias_b=None, res=None, mg_src=None, out=None,
     k, c_out, c_in_w = w.shape
     assert c_in_w == c_in, (tuple(x.shape), tuple(w.shape))
     # the kernel shares one row pitch between y, res and mg_src: enforce it here too
-    y_cols = gate_h if (flags & 32) else (2 * gate_h if (flags & 64) else c_out)
+    y_cols = gate_h if (flags & (32 | 1024)) else (2 * gate_h if (flags & 64) else c_out)
     ldy = out.stride(1) if out is not None else y_cols
     for tns in (res, mg_src):
         assert tns is None or tns.stride(1) == ldy, "res / mg_src row pitch must equal the output's"
@@ -47,6 +47,15 @@ def conv1d_cl_raw(x, w, bias=None, bias_b=None, res=None, mg_src=None, out=None,
     rowmask = None
     if lengths is not None:
         rowmask = (torch.arange(v.size(1), device=x.device)[None, :, None] < lengths[:, None, None])
+    if flags & 1024:                                                   # RES_SKIP: res half -> y, skip half (+)= out2
+        H = gate_h
+        r_ = ((v[..., :H] + res.float()) * rowmask).to(x.dtype)
+        sk = v[..., H:] * rowmask
+        out2.copy_((out2.float() + sk if flags & 8 else sk).to(x.dtype))
+        if out is not None:
+            out.copy_(r_)
+            return out
+        return r_.contiguous()
     if flags & 32:                                                     # GATE
         if out2 is not None:
             out2.copy_(v.to(x.dtype))

@@ -22,7 +22,7 @@ ft = tr.FineTuner(hps, "cuda:0", amp=os.environ.get("FP32") != "1")
 if os.environ.get("BRANCHES") is not None:
     ft.side_branches = frozenset(b for b in os.environ["BRANCHES"].split(",") if b)
 batch = tr.synthetic_batch(hps, batch_size, t_y_range, "cuda:0")
-ft.capture(batch, warmup=3)
+ft.capture(batch, warmup=3, verify=False)
 ts = ft._state_tensors()
 snap = [t.detach().clone() for t in ts]
 rng = torch.cuda.get_rng_state(ft.device)

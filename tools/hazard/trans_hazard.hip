@@ -102,6 +102,36 @@ __global__ void victim4(float* worst, int iters) {
   worst[e] = w;
 }
 
+// Packed fp32 with a scalar operand, the instruction that fed the wrong stores (v_pk_mul_f32 v[..], s[0:1], v[..] op_sel_hi:[0,1]):
+//   KIND 0: s_mov s10, h ; s_mov s11, junk ; v_pk_mul_f32 (SALU write right in front of the read)
+//   KIND 1: v_pk_mul_f32 ; s_mov s10, junk ; s_mov s11, junk (SALU overwrites the pair right behind the read)
+//   KIND 2: both
+template <int KINDV>
+__global__ void victim5(float* worst, int iters) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  float a = 1.0f + 0.001f * (float)(threadIdx.x & 63), w = 0.f;
+  const float hs = 0.0721687836f, junk = 12345.0f;
+  for (int it = 0; it < iters; ++it) {
+    float r0, r1;
+    const float a1 = a * 1.5f;
+    if (KINDV == 0)
+      asm volatile("v_mov_b32 v6, %2\n v_mov_b32 v7, %3\n s_nop 4\n s_mov_b32 s10, %4\n s_mov_b32 s11, %5\n"
+                   "v_pk_mul_f32 v[4:5], s[10:11], v[6:7] op_sel_hi:[0,1]\n s_nop 7\n v_mov_b32 %0, v4\n v_mov_b32 %1, v5\n"
+                   : "=v"(r0), "=v"(r1) : "v"(a), "v"(a1), "s"(hs), "s"(junk) : "v4", "v5", "v6", "v7", "s10", "s11");
+    else if (KINDV == 1)
+      asm volatile("v_mov_b32 v6, %2\n v_mov_b32 v7, %3\n s_mov_b32 s10, %4\n s_mov_b32 s11, %5\n s_nop 4\n"
+                   "v_pk_mul_f32 v[4:5], s[10:11], v[6:7] op_sel_hi:[0,1]\n s_mov_b32 s10, %5\n s_mov_b32 s11, %5\n s_nop 7\n v_mov_b32 %0, v4\n v_mov_b32 %1, v5\n"
+                   : "=v"(r0), "=v"(r1) : "v"(a), "v"(a1), "s"(hs), "s"(junk) : "v4", "v5", "v6", "v7", "s10", "s11");
+    else
+      asm volatile("v_mov_b32 v6, %2\n v_mov_b32 v7, %3\n s_nop 4\n s_mov_b32 s10, %4\n s_mov_b32 s11, %5\n"
+                   "v_pk_mul_f32 v[4:5], s[10:11], v[6:7] op_sel_hi:[0,1]\n s_mov_b32 s10, %5\n s_mov_b32 s11, %5\n s_nop 7\n v_mov_b32 %0, v4\n v_mov_b32 %1, v5\n"
+                   : "=v"(r0), "=v"(r1) : "v"(a), "v"(a1), "s"(hs), "s"(junk) : "v4", "v5", "v6", "v7", "s10", "s11");
+    w = fmaxf(w, fmaxf(fabsf(r0 - hs * a), fabsf(r1 - hs * a1)));
+    a += 0.0001f;
+  }
+  worst[e] = w;
+}
+
 __global__ void aggressor(float* out, int iters) {
   float v = 0.001f * (float)threadIdx.x, acc = 0.f;
   for (int it = 0; it < iters; ++it) {
@@ -125,7 +155,8 @@ static void run(const char* name, int mode) {          // mode 0: 1 wave per SIM
   float maxerr = 0.f;
   for (int r = 0; r < rounds; ++r) {
     if (mode == 1 || mode == 2) hipLaunchKernelGGL(aggressor, dim3(2048), dim3(mode == 1 ? 256 : 1024), 0, s1, junk, 4000);
-    if (KIND == 3) hipLaunchKernelGGL(victim4<NOPS>, dim3(blocks), dim3(threads), 0, s0, worst, iters);
+    if (KIND == 4) hipLaunchKernelGGL(victim5<NOPS>, dim3(blocks), dim3(threads), 0, s0, worst, iters);
+    else if (KIND == 3) hipLaunchKernelGGL(victim4<NOPS>, dim3(blocks), dim3(threads), 0, s0, worst, iters);
     else if (KIND == 2) hipLaunchKernelGGL(victim3<NOPS>, dim3(blocks), dim3(threads), 0, s0, worst, iters);
     else if (KIND == 1) hipLaunchKernelGGL(victim2<NOPS>, dim3(blocks), dim3(threads), 0, s0, worst, iters);
     else hipLaunchKernelGGL(victim<NOPS>, dim3(blocks), dim3(threads), 0, s0, worst, iters);
@@ -142,13 +173,12 @@ static void run(const char* name, int mode) {          // mode 0: 1 wave per SIM
 }
 
 int main() {
-  run<-1, 3>("WAR: rcp; overwrite src (no nop)", 0);
-  run<-1, 3>("WAR: rcp; overwrite src (no nop)", 1);
-  run<-1, 3>("WAR: rcp; overwrite src (no nop)", 3);
-  run<0, 3>("WAR: rcp; s_nop 0; overwrite src", 0);
-  run<0, 3>("WAR: rcp; s_nop 0; overwrite src", 3);
-  run<1, 3>("WAR: rcp; s_nop 1; overwrite src", 3);
-  run<4, 3>("WAR: rcp; s_nop 4; overwrite src", 3);
-  run<15, 3>("WAR: rcp; 16 nops; overwrite src", 3);
+  run<0, 4>("pk_mul: SALU write in front", 0);
+  run<0, 4>("pk_mul: SALU write in front", 1);
+  run<0, 4>("pk_mul: SALU write in front", 3);
+  run<1, 4>("pk_mul: SALU overwrite behind", 0);
+  run<1, 4>("pk_mul: SALU overwrite behind", 1);
+  run<1, 4>("pk_mul: SALU overwrite behind", 3);
+  run<2, 4>("pk_mul: both", 3);
   return 0;
 }

@@ -12,7 +12,7 @@ ft = tr.FineTuner(hps, "cuda:0", amp=True)
 if len(sys.argv) > 2:
     ft.side_branches = frozenset(b for b in sys.argv[2].split(",") if b)
 batch = tr.synthetic_batch(hps, batch_size, t_y_range, "cuda:0")
-ft.capture(batch)
+ft.capture(batch, verify=False)
 bad = 0
 for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):
     try:
