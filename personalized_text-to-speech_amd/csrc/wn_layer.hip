@@ -661,9 +661,11 @@ extern "C" int vits_wn_layer_fwd(const vits_wn_layer_desc* desc, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int nt = vits::ceil_div(d.h, 64);
   if (d.dtype == VITS_DT_BF16) {
-    if (nt == 1) return launch_fwd<__bf16, 1, 2>(d, s);
-    if (nt == 2) return launch_fwd<__bf16, 2, 2>(d, s);
-    return launch_fwd<__bf16, 3, 2>(d, s);
+    // 64-row tiles only when they still give every CU a workgroup; else 32-row tiles (twice the workgroups, half the LDS)
+    const bool small = (long)vits::ceil_div(d.t, 64) * d.b < 256;
+    if (nt == 1) return small ? launch_fwd<__bf16, 1, 1>(d, s) : launch_fwd<__bf16, 1, 2>(d, s);
+    if (nt == 2) return small ? launch_fwd<__bf16, 2, 1>(d, s) : launch_fwd<__bf16, 2, 2>(d, s);
+    return small ? launch_fwd<__bf16, 3, 1>(d, s) : launch_fwd<__bf16, 3, 2>(d, s);
   }
   if (nt == 1) return launch_fwd<float, 1, 1>(d, s);
   if (nt == 2) return launch_fwd<float, 2, 1>(d, s);
@@ -689,9 +691,11 @@ extern "C" int vits_wn_layer_bwd(const vits_wn_layer_bwd_desc* desc, void* strea
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int nt = vits::ceil_div(d.h, 64);
   if (d.dtype == VITS_DT_BF16) {
-    if (nt == 1) return launch_bwd<__bf16, 4, 1>(d, s);
-    if (nt == 2) return launch_bwd<__bf16, 4, 2>(d, s);
-    return launch_bwd<__bf16, 4, 3>(d, s);
+    const int halo = (d.k - 1) * d.dil;
+    const bool small = halo < 32 && (long)vits::ceil_div(d.t, 64 - halo) * d.b < 256;
+    if (nt == 1) return small ? launch_bwd<__bf16, 2, 1>(d, s) : launch_bwd<__bf16, 4, 1>(d, s);
+    if (nt == 2) return small ? launch_bwd<__bf16, 2, 2>(d, s) : launch_bwd<__bf16, 4, 2>(d, s);
+    return small ? launch_bwd<__bf16, 2, 3>(d, s) : launch_bwd<__bf16, 4, 3>(d, s);
   }
   if (nt == 1) return launch_bwd<float, 2, 1>(d, s);
   if (nt == 2) return launch_bwd<float, 2, 2>(d, s);

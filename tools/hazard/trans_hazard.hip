@@ -173,11 +173,19 @@ static void run(const char* name, int mode) {          // mode 0: 1 wave per SIM
 }
 
 int main() {
-  run<0, 4>("pk_mul: SALU write in front", 0);
-  run<0, 4>("pk_mul: SALU write in front", 1);
+  // mode 0: two waves per workgroup, 52 workgroups, alone; 1: + a transcendental-heavy kernel on a second stream; 3: the victim itself
+  // with 8 waves per SIMD (its waves contend with each other for the issue ports and the transcendental pipe)
+  run<-1>("RAW: rcp; fma (no wait state)", 0);                 // wrong in every lane: the hardware does not interlock this
+  run<0>("RAW: rcp; s_nop 0; fma", 0);
+  run<0>("RAW: rcp; s_nop 0; fma", 1);
+  run<0>("RAW: rcp; s_nop 0; fma", 3);
+  run<0, 1>("RAW: rcp; rcp; s_nop 0; fma on 2nd", 1);
+  run<0, 1>("RAW: rcp; rcp; s_nop 0; fma on 2nd", 3);
+  run<0, 2>("RAW: rcp; rcp; s_nop 0; v_pk_fma", 1);
+  run<0, 2>("RAW: rcp; rcp; s_nop 0; v_pk_fma", 3);
+  run<-1, 3>("WAR: rcp; overwrite src (no nop)", 1);
+  run<-1, 3>("WAR: rcp; overwrite src (no nop)", 3);
   run<0, 4>("pk_mul: SALU write in front", 3);
-  run<1, 4>("pk_mul: SALU overwrite behind", 0);
-  run<1, 4>("pk_mul: SALU overwrite behind", 1);
   run<1, 4>("pk_mul: SALU overwrite behind", 3);
   run<2, 4>("pk_mul: both", 3);
   return 0;
