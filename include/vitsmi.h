@@ -181,16 +181,17 @@ typedef struct vits_wgrad_pending {
 int vits_conv1d_cl_wgrad_deferred(const vits_wgrad_desc* desc, void* stream, vits_wgrad_pending* pending);
 int vits_wgrad_reduce_pending(const vits_wgrad_pending* list, int count, void* stream);
 
-/* The weight (+ bias) gradients of a GROUP of stride-1 "same" convolutions (t_out == t, groups == 1) in one launch per
- * taps-per-group class (csrc/conv1d_wgrad_batch.hip): the layers of a stack are each other's parallelism, so with enough 64 x 64
- * tiles in the group every workgroup walks its whole (b, t) reduction and nothing but dw is written (no per-split slabs).
- * descs[i] are ordinary vits_wgrad_desc (same dtype); `workspace` is only used when the group is too small to fill the chip:
- * then the reduction is split vits_conv1d_cl_wgrad_batch_splits(descs, count) ways — give every entry a workspace of at least
- * splits * (k*c_out*c_in + c_out) floats and a `pending` array of `count` entries (pending[i].splits == 0: entry i is final),
- * and run vits_wgrad_reduce_pending on it afterwards; without workspace / pending the entries run unsplit.
+/* The weight (+ bias) gradients of a GROUP of stride-1 "same" convolutions (t_out == t, groups == 1; in_slope as in
+ * vits_conv1d_cl_wgrad) in one launch per taps-per-group class (csrc/conv1d_wgrad_batch.hip): the layers of a stack are each
+ * other's parallelism, so with enough 64 x 64 tiles in the group every workgroup walks its whole (b, t) reduction and nothing but
+ * dw is written (no per-split slabs).  descs[i] are ordinary vits_wgrad_desc (same dtype).  Entries with a long reduction over
+ * few tiles are still split: vits_conv1d_cl_wgrad_batch_plan(descs, count, splits) tells how many slabs entry i will use —
+ * give every entry with splits[i] > 1 a `workspace` of at least splits[i] * (k*c_out*c_in + c_out) floats and pass a `pending`
+ * array of `count` entries (pending[i].splits == 0 afterwards: entry i is final), then run vits_wgrad_reduce_pending on it;
+ * an entry without workspace / pending runs unsplit.
  * Returns VITS_E_UNSUPPORTED if any entry is not eligible (strided, grouped, dilated beyond the staged halo ...): the caller
  * then issues the per-layer calls. */
-int vits_conv1d_cl_wgrad_batch_splits(const vits_wgrad_desc* descs, int count);
+int vits_conv1d_cl_wgrad_batch_plan(const vits_wgrad_desc* descs, int count, int* splits_out);
 int vits_conv1d_cl_wgrad_batch(const vits_wgrad_desc* descs, int count, void* stream, vits_wgrad_pending* pending);
 
 /* ------------------------------------------------------------------------------------------

@@ -48,7 +48,7 @@ SIGNATURES = {
     "vits_conv1d_cl_wgrad": (c_int, [c_void_p, c_void_p]),
     "vits_conv1d_cl_wgrad_deferred": (c_int, [c_void_p, c_void_p, c_void_p]),
     "vits_wgrad_reduce_pending": (c_int, [c_void_p, c_int, c_void_p]),
-    "vits_conv1d_cl_wgrad_batch_splits": (c_int, [c_void_p, c_int]),
+    "vits_conv1d_cl_wgrad_batch_plan": (c_int, [c_void_p, c_int, c_void_p]),
     "vits_conv1d_cl_wgrad_batch": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "vits_conv1d_cl": (c_int, [c_void_p, c_void_p]),
     "vits_wn_layer_fwd": (c_int, [c_void_p, c_void_p]),

@@ -36,6 +36,7 @@ struct Entry {
   unsigned long long slab;       // floats per split slab (dw then db); 0 when S == 1
   int B, T, Cin, Cout, K, dil, pad, ldx, lddy, flags;
   int tiles_co, tiles_ci, tap_groups, S, first_block, accumulate;
+  float in_slope;                // fused leaky-relu on x (1 = none), applied when the chunk is written to LDS
 };
 struct Table { Entry e[kMaxBatch]; int n; };
 
@@ -45,6 +46,22 @@ template <> struct Pitch<float> { static constexpr int value = CT * 4 + 16; };
 
 __device__ __forceinline__ float to_f(float v) { return v; }
 __device__ __forceinline__ float to_f(__bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ __bf16 from_f<__bf16>(float v) { return (__bf16)v; }
+
+template <typename T>
+__device__ __forceinline__ u32x4 lrelu_vec(u32x4 raw, float slope) {
+  constexpr int V = 16 / sizeof(T);
+  union { u32x4 u; T e[V]; } in, out;
+  in.u = raw;
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const float f = to_f(in.e[i]);
+    out.e[i] = from_f<T>(f > 0.f ? f : f * slope);
+  }
+  return out.u;
+}
 
 template <typename T, int KT>
 __global__ __launch_bounds__(kThreads, 2) void wgrad_batch_kernel(Table tab) {
@@ -90,6 +107,7 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_batch_kernel(Table tab) {
     xoff[i] = (row < xrows && ci0 + vc * V < a.Cin) ? (unsigned)((row * a.ldx + ci0 + vc * V) * ES) : 0xFFFFFFFFu;
   }
 
+  const bool lrelu = a.in_slope != 1.0f;
   u32x4 dr[2][DV], xr[2][XV];
   auto load_chunk = [&](int ch, u32x4 (&d)[DV], u32x4 (&x)[XV]) {
     // a chunk index beyond the end loads chunk 0's addresses with an empty range: every load stays unconditional
@@ -125,7 +143,7 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_batch_kernel(Table tab) {
 #pragma unroll
     for (int i = 0; i < XV; ++i) {
       const int idx = tid + i * kThreads;
-      if (idx < XROWS_MAX * VPR) *reinterpret_cast<u32x4*>(ldsX + (idx / VPR) * PITCH + (idx % VPR) * 16) = x[i];
+      if (idx < XROWS_MAX * VPR) *reinterpret_cast<u32x4*>(ldsX + (idx / VPR) * PITCH + (idx % VPR) * 16) = lrelu ? lrelu_vec<T>(x[i], a.in_slope) : x[i];
     }
   };
 
@@ -280,24 +298,47 @@ bool eligible(const vits_wgrad_desc& d) {
 
 }  // namespace
 
-// Splits a group of `count` entries would run with (1 = no slabs): the launcher's rule, exported so that the caller can size the
-// workspaces of the entries before the call.
-extern "C" int vits_conv1d_cl_wgrad_batch_splits(const vits_wgrad_desc* descs, int count) {
-  if (!descs || count <= 0) return 1;
-  long tiles = 0;
-  int chunks_min = 1 << 30;
-  for (int i = 0; i < count; ++i) {
-    const vits_wgrad_desc& d = descs[i];
-    tiles += (long)vits::ceil_div(d.c_out, CT) * vits::ceil_div(d.c_in, CT) * vits::ceil_div(d.k, taps_per_group(d.k));
-    const int chunks = d.b * vits::ceil_div(d.t, TK);
-    if (chunks < chunks_min) chunks_min = chunks;
+namespace {
+// Splits of the (b, t) reduction per entry of ONE launch group: every workgroup should walk about the same number of 128-row
+// chunks, about 1.25 resident rounds of workgroups in all (2 workgroups per CU by registers and LDS).  A group whose tiles alone
+// fill the chip runs unsplit (S = 1: nothing but dw is written); long reductions over few tiles (the decoder's last stages:
+// 1 tile x 1024 chunks) are cut into up to 64 slabs.
+void plan_group(const vits_wgrad_desc* g, int m, int kt, int* S) {
+  double work = 0;
+  for (int j = 0; j < m; ++j) {
+    const double tiles = (double)vits::ceil_div(g[j].c_out, CT) * vits::ceil_div(g[j].c_in, CT) * vits::ceil_div(g[j].k, kt);
+    work += tiles * g[j].b * vits::ceil_div(g[j].t, TK);
   }
-  // two workgroups per CU by registers and LDS: 512 slots.  Enough tiles for 3/4 of a round: no splits.
-  if (tiles >= 384) return 1;
-  int s = (int)(512 / tiles);
-  if (s > chunks_min) s = chunks_min;
-  if (s > 64) s = 64;
-  return s < 1 ? 1 : s;
+  int per_wg = (int)(work / 640.0) + 1;                 // chunks one workgroup should walk
+  if (per_wg < 8) per_wg = 8;
+  for (int j = 0; j < m; ++j) {
+    const int chunks = g[j].b * vits::ceil_div(g[j].t, TK);
+    int s = vits::ceil_div(chunks, per_wg);
+    if (s > 64) s = 64;
+    if (s > chunks) s = chunks;
+    S[j] = s < 1 ? 1 : s;
+  }
+}
+}  // namespace
+
+// splits_out[i] = the number of slabs entry i of a vits_conv1d_cl_wgrad_batch call over the same array will use (1 = none): the
+// caller gives every entry with splits > 1 a workspace of splits * (k*c_out*c_in + c_out) floats.
+extern "C" int vits_conv1d_cl_wgrad_batch_plan(const vits_wgrad_desc* descs, int count, int* splits_out) {
+  if (!descs || count <= 0 || count > 1024 || !splits_out) return VITS_E_BADARG;
+  bool done[1024] = {false};
+  for (int i0 = 0; i0 < count; ++i0) {
+    if (done[i0]) continue;
+    const int kt = taps_per_group(descs[i0].k);
+    int sel[kMaxBatch], m = 0;
+    for (int i = i0; i < count && m < kMaxBatch; ++i)
+      if (!done[i] && taps_per_group(descs[i].k) == kt) { sel[m++] = i; done[i] = true; }
+    vits_wgrad_desc grp[kMaxBatch];
+    int S[kMaxBatch];
+    for (int j = 0; j < m; ++j) grp[j] = descs[sel[j]];
+    plan_group(grp, m, kt, S);
+    for (int j = 0; j < m; ++j) splits_out[sel[j]] = S[j];
+  }
+  return VITS_OK;
 }
 
 extern "C" int vits_conv1d_cl_wgrad_batch(const vits_wgrad_desc* descs, int count, void* stream, vits_wgrad_pending* pending) {
@@ -319,14 +360,15 @@ extern "C" int vits_conv1d_cl_wgrad_batch(const vits_wgrad_desc* descs, int coun
       if (!done[i] && taps_per_group(descs[i].k) == kt) { sel[m++] = i; done[i] = true; }
     vits_wgrad_desc grp[kMaxBatch];
     for (int j = 0; j < m; ++j) grp[j] = descs[sel[j]];
-    int S = vits_conv1d_cl_wgrad_batch_splits(grp, m);
+    int S[kMaxBatch];
+    plan_group(grp, m, kt, S);
     Table tab;
     tab.n = m;
     int blocks = 0;
     for (int j = 0; j < m; ++j) {
       const vits_wgrad_desc& d = grp[j];
       const size_t n = (size_t)d.k * d.c_out * d.c_in, nb = d.dbias ? (size_t)d.c_out : 0;
-      int Sj = S;
+      int Sj = S[j];
       if (Sj > 1 && (!pending || !d.workspace || d.workspace_bytes < (size_t)Sj * (n + nb) * sizeof(float))) Sj = 1;   // no room for slabs
       Entry& e = tab.e[j];
       e.x = d.x; e.dy = d.dy; e.dw = d.dw; e.db = d.dbias; e.partial = static_cast<float*>(d.workspace); e.lengths = d.lengths;
@@ -335,6 +377,7 @@ extern "C" int vits_conv1d_cl_wgrad_batch(const vits_wgrad_desc* descs, int coun
       e.ldx = d.ldx > 0 ? d.ldx : d.c_in; e.lddy = d.lddy > 0 ? d.lddy : d.c_out; e.flags = d.flags;
       e.tiles_co = vits::ceil_div(d.c_out, CT); e.tiles_ci = vits::ceil_div(d.c_in, CT); e.tap_groups = vits::ceil_div(d.k, kt);
       e.S = Sj; e.first_block = blocks; e.accumulate = (d.flags & VITS_CONV_ACCUM) ? 1 : 0;
+      e.in_slope = d.in_slope;
       blocks += e.tiles_co * e.tiles_ci * e.tap_groups * Sj;
       if (Sj > 1) pending[sel[j]] = vits_wgrad_pending{e.partial, d.dw, d.dbias, n, nb, (size_t)e.slab, Sj, e.accumulate};
     }

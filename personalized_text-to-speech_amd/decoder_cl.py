@@ -168,12 +168,19 @@ class DecoderFn(torch.autograd.Function):
         def flip_t(r):                       # data-gradient operand of weight slot r
             return WA.bwd_operand(R[r])
 
+        batch = []                           # the weight gradients of the whole decoder: launched together at the end
+
         def WGo(x, dy, k, slot, bias_slot=None, **kw):     # weight gradient into the arena's dw region when there is one;
             db = None                                      # the bias gradient (column sums of dy) rides in the same launch
             if bias_slot is not None:
                 db = torch.empty(dy.size(2), dtype=torch.float32, device=dy.device)
                 grads[bias_slot] = db
-            return WG(x, dy, k, out=R[slot].claim_dw(ctx), dbias=db, defer=defer, **kw)
+            out = R[slot].claim_dw(ctx)
+            if out is None:
+                out = torch.empty(k, dy.size(2), x.size(2), dtype=torch.float32, device=dy.device)
+            # (x and dy stay referenced by the batch until it is launched: the intermediate gradients are fresh tensors)
+            batch.append(dict(x=x, dy=dy if dy.is_contiguous() else dy.contiguous(), k=k, out=out, dbias=db, **kw))
+            return out
 
         def bias_grad(d):
             return K.colsum(d if d.is_contiguous() else d.contiguous())
@@ -230,6 +237,10 @@ class DecoderFn(torch.autograd.Function):
         grads[i_pre[0]] = WGo(z, dh, 7, i_pre[0], i_pre[1], pad=3)
         dz = C(dh, flip_t(i_pre[0]), None, pad=3)
         dcond = K.colsum(dh if dh.is_contiguous() else dh.contiguous(), per_item=True) if ctx.has_cond else None
+        if not K.conv1d_cl_wgrad_batch(batch, defer):
+            for e in batch:                                         # (not eligible: one launch per convolution)
+                WG(e["x"], e["dy"], e["k"], dil=e.get("dil", 1), pad=e.get("pad", 0), in_slope=e.get("in_slope", 1.0), out=e["out"],
+                   dbias=e["dbias"], defer=defer)
         defer.flush()
         return (None, None, dz, dcond, *grads)
 

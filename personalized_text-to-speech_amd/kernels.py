@@ -779,7 +779,7 @@ def conv1d_cl_wgrad_raw(x, dy, k, lengths=None, dil=1, pad=0, stride=1, in_slope
 def conv1d_cl_wgrad_batch(entries, defer=None):
     """The weight (+ bias) gradients of a group of stride-1 "same" convolutions in one launch per taps-per-group class
     (vits_conv1d_cl_wgrad_batch, csrc/conv1d_wgrad_batch.hip).  entries: dicts with x [b,t,c_in], dy [b,t,c_out], k, out
-    (fp32 [k,c_out,c_in], written), and optionally dbias (fp32 [c_out]), lengths, dil, pad, flags.  With enough tiles in the
+    (fp32 [k,c_out,c_in], written), and optionally dbias (fp32 [c_out]), lengths, dil, pad, flags, in_slope.  With enough tiles in the
     group nothing but `out` is written; a small group splits the reduction into slabs, which need `defer` (a
     DeferredReductions collector: the caller flushes it).  Returns False when an entry is not eligible (nothing was launched)."""
     import ctypes
@@ -797,27 +797,21 @@ def conv1d_cl_wgrad_batch(entries, defer=None):
         assert db is None or (db.dtype == torch.float32 and db.is_contiguous() and db.numel() == c_out)
         d.dtype, d.b, d.t, d.c_in, d.c_out, d.k = _DT[x.dtype], b, t, c_in, c_out, k
         d.dil, d.pad, d.stride, d.flags = e.get("dil", 1), e.get("pad", 0), 1, int(e.get("flags", 0))
-        d.ldx, d.lddy, d.in_slope, d.groups = _rows(x, "x"), _rows(dy, "dy"), 1.0, 1
+        d.ldx, d.lddy, d.in_slope, d.groups = _rows(x, "x"), _rows(dy, "dy"), float(e.get("in_slope", 1.0)), 1
         d.x, d.dy, d.dw = x.data_ptr(), dy.data_ptr(), out.data_ptr()
         d.lengths = None if lengths is None else lengths.data_ptr()
         d.dbias = None if db is None else db.data_ptr()
-    # slabs only when the group is too small to fill the chip without splitting its reductions
+    # slabs only for entries whose reduction the launcher will split (long reductions over few tiles)
     pend = None
-    by_class = {}
-    for i, e in enumerate(entries):
-        by_class.setdefault(min(e["k"], 4) if e["k"] <= 4 else ((e["k"] + 1) // 2 if e["k"] <= 8 else 4), []).append(i)
     if defer is not None:
-        for idxs in by_class.values():
-            grp = (_lib.WgradDesc * len(idxs))(*[descs[i] for i in idxs])
-            S = L.vits_conv1d_cl_wgrad_batch_splits(ctypes.addressof(grp), len(idxs))
+        splits = (ctypes.c_int * n)()
+        _lib.check(L.vits_conv1d_cl_wgrad_batch_plan(ctypes.addressof(descs), n, ctypes.addressof(splits)), "vits_conv1d_cl_wgrad_batch_plan")
+        for d, S in zip(descs, splits):
             if S > 1:
-                for i in idxs:
-                    d = descs[i]
-                    nbytes = S * (d.k * d.c_out * d.c_in + (d.c_out if d.dbias else 0)) * 4
-                    ws = defer.alloc(nbytes)
-                    if ws is not None:
-                        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
-                pend = pend or (_lib.WgradPending * n)()
+                ws = defer.alloc(S * (d.k * d.c_out * d.c_in + (d.c_out if d.dbias else 0)) * 4)
+                if ws is not None:
+                    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+                    pend = pend or (_lib.WgradPending * n)()
     e0 = _lib.timer.start("vits_conv1d_cl_wgrad")
     rc = L.vits_conv1d_cl_wgrad_batch(ctypes.addressof(descs), n, _lib.stream_ptr(), None if pend is None else ctypes.addressof(pend))
     if rc == _lib.E_UNSUPPORTED:

@@ -58,6 +58,15 @@ class FineTuner:
         self.net_g.train()
         self.net_d.train()
 
+    @staticmethod
+    def _capture_mode():
+        """Error mode of a graph capture.  With an initialised process group RCCL's watchdog thread polls events all the time;
+        under the default "global" mode its hipEventQuery during our capture is an illegal call that takes the process down
+        ("operation not permitted when stream is capturing" — found by tests/test_rccl_single_gpu.py, the first time the nccl
+        branches ran).  "thread_local" confines the check to the capturing thread."""
+        import torch.distributed as dist
+        return "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+
     def _autocast(self):
         if self.amp and self.device.type == "cuda":
             return torch.autocast("cuda", dtype=torch.bfloat16)
@@ -172,7 +181,7 @@ class FineTuner:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
+        with torch.cuda.graph(self._graph, capture_error_mode=self._capture_mode()):
             self._static_out = self.step(batch)
         _lib.timer.enabled = timer_was
         if verify:
@@ -199,13 +208,14 @@ class FineTuner:
         self.buckets_d.manual(True)
         self.buckets_g.manual(True)
         ga, gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(ga):
+        mode = self._capture_mode()
+        with torch.cuda.graph(ga, capture_error_mode=mode):
             self._phase_a(batch)
             self.buckets_d.pack()
-        with torch.cuda.graph(gb, pool=ga.pool()):
+        with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode=mode):
             self._phase_b()
             self.buckets_g.pack()
-        with torch.cuda.graph(gc, pool=ga.pool()):
+        with torch.cuda.graph(gc, pool=ga.pool(), capture_error_mode=mode):
             self._static_out = self._phase_c()
         self._graph = (ga, gb, gc)
         _lib.timer.enabled = timer_was
@@ -322,7 +332,7 @@ class FineTuner:
             ent["batch"] = tuple(t.clone() for t in padded)
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
-            with torch.cuda.graph(g, pool=self._graph_pool, stream=cs):
+            with torch.cuda.graph(g, pool=self._graph_pool, stream=cs, capture_error_mode=self._capture_mode()):
                 ent["out"] = self.step(ent["batch"])
             if self._graph_pool is None:
                 self._graph_pool = g.pool()

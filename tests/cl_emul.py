@@ -411,7 +411,7 @@ def conv1d_cl_wgrad_batch(entries, defer=None):
     """vits_conv1d_cl_wgrad_batch: every entry is an ordinary weight (+ bias) gradient."""
     for e in entries:
         conv1d_cl_wgrad_raw(e["x"], e["dy"], e["k"], lengths=e.get("lengths"), dil=e.get("dil", 1), pad=e.get("pad", 0),
-                            flags=e.get("flags", 0), out=e["out"], dbias=e.get("dbias"))
+                            in_slope=e.get("in_slope", 1.0), flags=e.get("flags", 0), out=e["out"], dbias=e.get("dbias"))
     return True
 
 

@@ -10,9 +10,11 @@ from model_util import rel_err
 pytestmark = pytest.mark.gpu
 
 
-def _torch_wgrad(x, dy, k, dil, pad, lengths, flags):
+def _torch_wgrad(x, dy, k, dil, pad, lengths, flags, in_slope=1.0):
     b, t, c_in = x.shape
     xf, dyf = x.float(), dy.float()
+    if in_slope != 1.0:
+        xf = F.leaky_relu(xf, in_slope)
     m = None if lengths is None else (torch.arange(t, device=x.device)[None, :, None] < lengths[:, None, None])
     if flags & 1:
         xf = xf * m
@@ -70,6 +72,23 @@ def test_small_group_splits_into_slabs_and_equals_the_per_layer_kernel(pkg):
     assert K.conv1d_cl_wgrad_batch(e, None)
     gw, gb = _torch_wgrad(e[7]["x"], e[7]["dy"], 3, 1, 1, None, 0)
     assert rel_err(e[7]["out"], gw + 1.5) < 2e-5 and rel_err(e[7]["dbias"], gb - 2.0) < 2e-5
+
+
+def test_decoder_like_group_long_reductions_split_and_input_activation(pkg):
+    """The decoder's shapes: few tiles x very long reductions (t = 4096, 32 / 64 channels, k = 3 / 7 / 11, dilations, fused
+    leaky-relu on the input): the launcher splits such entries into slabs while wide entries of the same call stay unsplit."""
+    K = pkg.kernels
+    shapes = [(64, 64, 7, 3, 0), (64, 64, 11, 5, 0), (32, 32, 11, 1, 0), (256, 256, 7, 1, 0), (256, 256, 11, 3, 0), (128, 128, 3, 5, 0)]
+    ents = _entries(torch.bfloat16, shapes, 2, 4096, seed=3)
+    for e in ents:
+        e["in_slope"] = 0.1
+    defer = K.DeferredReductions(ents[0]["x"].device)
+    assert K.conv1d_cl_wgrad_batch(ents, defer)
+    assert defer.pending
+    defer.flush()
+    for e in ents:
+        gw, gb = _torch_wgrad(e["x"], e["dy"], e["k"], e["dil"], e["pad"], None, 0, in_slope=0.1)
+        assert rel_err(e["out"], gw) < 2e-2 and rel_err(e["dbias"], gb) < 2e-2, (e["k"], e["dil"])
 
 
 def test_ineligible_entries_are_refused(pkg):
