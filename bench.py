@@ -249,12 +249,9 @@ def main():
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             return int(flag) == 1
 
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
+        with tuner.on_capture_stream():                  # (the stream the captures use: FineTuner.on_capture_stream)
             for _ in range(3):
                 tuner.step(batch)
-        torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         why = None
         try:

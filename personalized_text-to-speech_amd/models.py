@@ -553,8 +553,12 @@ class SynthesizerTrn(nn.Module):
     def _forward(self, x, x_lengths, y, y_lengths, sid=None):
         # The text encoder (~600 launches on [b, t_x, 192] tensors, forward + backward) and the posterior encoder + flow do not
         # depend on each other until the alignment: two branches (kernels.SideBranch), forward and — because every backward
-        # runs on its forward's stream — backward.
-        enc_branch = K.SideBranch(x.device, x, x_lengths, lane=1) if ("enc_p" in self.side_branches and x.is_cuda) else None
+        # runs on its forward's stream — backward.  Both branches use ONE side stream (lane 0; they never need each other's time:
+        # this one is joined before the alignment, the duration predictor's is opened after it): with a lane each, the HIP
+        # runtime may or may not give the two lanes separate hardware queues (it depends on the order streams were created in),
+        # and three queues competing cost the main chain more than the extra overlap returns — 24.5 against 21.8 ms/step (C2,
+        # round 3; rocprofv3 queue ids, tools/queue_summary.py).
+        enc_branch = K.SideBranch(x.device, x, x_lengths, lane=0) if ("enc_p" in self.side_branches and x.is_cuda) else None
         if enc_branch is not None:
             enc_branch.__enter__()
         try:

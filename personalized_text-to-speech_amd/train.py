@@ -51,12 +51,32 @@ class FineTuner:
         # (34.5 -> 27.3 ms/step together; replays bitwise reproducible — DESIGN.md §6b tells how the "dp" branch exposed the
         # spline kernel's irreproducibility under concurrency and what cured it).  Also available, off: "mel" (slower).
         self.side_branches = frozenset(("enc_p", "dp"))
-        self.buckets_g = GradBuckets(self.net_g.parameters(), bucket_bytes, force=force_exchange)
-        self.buckets_d = GradBuckets(self.net_d.parameters(), bucket_bytes, force=force_exchange)
+        # One stream for everything that is ever captured (warm-up steps, captures, the bucket hooks' registration): autograd
+        # runs a parameter's AccumulateGrad on the stream that was current when that node was CREATED and a post-accumulate
+        # hook pins the node, and a capture must not have to synchronise with the legacy default stream (step_padded).
+        self._capture_stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
+        self._graph_pool = None
+        with self.on_capture_stream():
+            self.buckets_g = GradBuckets(self.net_g.parameters(), bucket_bytes, force=force_exchange)
+            self.buckets_d = GradBuckets(self.net_d.parameters(), bucket_bytes, force=force_exchange)
         self.sched_g = torch.optim.lr_scheduler.ExponentialLR(self.optim_g, gamma=hps.train.lr_decay)
         self.sched_d = torch.optim.lr_scheduler.ExponentialLR(self.optim_d, gamma=hps.train.lr_decay)
         self.net_g.train()
         self.net_d.train()
+
+    @contextlib.contextmanager
+    def on_capture_stream(self):
+        """Run the body on the tuner's capture stream, ordered after what the current stream holds and before what it does next
+        (eager warm-up steps of a run that will be captured belong here; a no-op on the CPU)."""
+        cs = self._capture_stream
+        if cs is None:
+            yield
+            return
+        cur = torch.cuda.current_stream(self.device)
+        cs.wait_stream(cur)
+        with torch.cuda.stream(cs):
+            yield
+        cur.wait_stream(cs)
 
     @staticmethod
     def _capture_mode():
@@ -173,16 +193,14 @@ class FineTuner:
         assert self.device.type == "cuda" and self._graph is None
         timer_was, _lib.timer.enabled = _lib.timer.enabled, False
         self._static_batch = batch
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
+        with self.on_capture_stream():
             for _ in range(warmup):
                 self.step(batch)
-        torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph, capture_error_mode=self._capture_mode()):
+        with torch.cuda.graph(self._graph, pool=self._graph_pool, stream=self._capture_stream, capture_error_mode=self._capture_mode()):
             self._static_out = self.step(batch)
+        self._graph_pool = self._graph.pool()
         _lib.timer.enabled = timer_was
         if verify:
             self.verify_replay()
@@ -197,25 +215,22 @@ class FineTuner:
         assert self.device.type == "cuda" and self._graph is None
         timer_was, _lib.timer.enabled = _lib.timer.enabled, False
         self._static_batch = batch
-        if warmup:                                   # (bench.py at N > 1 warms up itself: these steps issue collectives)
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(warmup):
-                    self.step(batch)
-            torch.cuda.current_stream().wait_stream(side)
+        with self.on_capture_stream():               # (bench.py at N > 1 warms up itself, the same way: these steps issue collectives)
+            for _ in range(warmup):
+                self.step(batch)
         torch.cuda.synchronize()
         self.buckets_d.manual(True)
         self.buckets_g.manual(True)
         ga, gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        mode = self._capture_mode()
-        with torch.cuda.graph(ga, capture_error_mode=mode):
+        mode, cs = self._capture_mode(), self._capture_stream
+        with torch.cuda.graph(ga, pool=self._graph_pool, stream=cs, capture_error_mode=mode):
             self._phase_a(batch)
             self.buckets_d.pack()
-        with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode=mode):
+        self._graph_pool = ga.pool()
+        with torch.cuda.graph(gb, pool=self._graph_pool, stream=cs, capture_error_mode=mode):
             self._phase_b()
             self.buckets_g.pack()
-        with torch.cuda.graph(gc, pool=ga.pool(), capture_error_mode=mode):
+        with torch.cuda.graph(gc, pool=self._graph_pool, stream=cs, capture_error_mode=mode):
             self._static_out = self._phase_c()
         self._graph = (ga, gb, gc)
         _lib.timer.enabled = timer_was
@@ -311,8 +326,6 @@ class FineTuner:
         # Everything — the eager first step of a shape too — runs on ONE non-default stream: autograd keeps the stream of the
         # step that created a parameter's AccumulateGrad node, and a capture that has to synchronise with the legacy default
         # stream is illegal (hipStreamEndCapture crashes on it; FineTuner.capture warms up on a side stream for the same reason).
-        if "_capture_stream" not in self.__dict__:
-            self._capture_stream, self._graph_pool = torch.cuda.Stream(self.device), None
         cs, cur = self._capture_stream, torch.cuda.current_stream(self.device)
         key = tuple(tuple(t.shape) for t in padded)
         cache = self.__dict__.setdefault("_shape_graphs", {})

@@ -75,12 +75,9 @@ def main():
     batch = make_batch(P, cfg, rank)
     losses = []
     keys = ("loss_disc", "loss_gen", "loss_fm", "loss_mel", "loss_dur", "loss_kl", "grad_norm_d", "grad_norm_g")
-    side = torch.cuda.Stream()                       # warm-up off the default stream, as torch asks before a graph capture
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
+    with ft.on_capture_stream():                     # warm-up off the default stream, on the stream the captures use
         torch.manual_seed(1000)
         out = ft.step(batch)
-    torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     losses.append([float(out[k]) for k in keys])
     if mode == "graph":
