@@ -67,7 +67,11 @@ __global__ __launch_bounds__(kThreads) void adamw_kernel(Table tab, float* __res
     inv_bc2_sqrt = 1.0f / sqrtf(bc2);
     decay = 1.0f - lr * h.weight_decay;
   }
+  // No contraction into fused multiply-adds here: left to the compiler, the float4 path and the scalar path of this kernel
+  // were contracted differently, and the same gradient gave parameters one ulp apart depending on whether its buffer was
+  // 16-byte aligned (found when data-parallel replays kept gradients in the arena while the eager step used bucket views).
   auto one = [&](float gi, float& p, float& m, float& v) {
+#pragma clang fp contract(off)
     p *= decay;                                         // decoupled weight decay
     m = m + (gi - m) * h.one_minus_beta1;               // exp_avg.lerp_(grad, 1 - beta1)
     v = v * h.beta2 + h.one_minus_beta2 * gi * gi;

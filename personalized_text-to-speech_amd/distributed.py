@@ -113,22 +113,72 @@ class GradBuckets:
     def manual(self, flag):
         self._manual = flag
 
+    INPLACE_MIN = 1 << 20        # bytes: a run of gradients that already lie back to back is exchanged where it is from this size on
+
     def pack(self):
-        """Copy every bucket's gradients into its flat buffer (one multi-tensor copy each) and point param.grad at the flat
-        views; graph-capturable (no collective)."""
-        for flat, plist, views in self.buckets:
-            have = [(v, p.grad) for v, p in zip(views, plist) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
-            missing = [v for v, p in zip(views, plist) if p.grad is None]
-            if missing:
-                torch._foreach_zero_(missing)
+        """Manual mode's gather step, graph-capturable (no collective).  Gradients that already lie back to back in one
+        allocation — the weight arenas write all of a network's convolution gradients into one flat buffer — are exchanged in
+        place: each such run of at least INPLACE_MIN bytes becomes a flat alias.  The rest (biases, norms, embeddings) is copied
+        into one flat leftover buffer by ONE multi-tensor copy and param.grad is pointed at its views.  Leaves
+        self._exchange = the flat tensors all_reduce() averages."""
+        self._exchange = []
+        if not self.active:
+            return
+        items, missing = [], []
+        for p in self.params:
+            g = p.grad
+            if g is None:
+                missing.append(p)
+            elif g.dtype == p.dtype and g.is_contiguous():
+                items.append((g.untyped_storage().data_ptr(), g.data_ptr(), g.numel() * g.element_size(), p))
+            else:
+                missing.append(p)                       # (copied below: not a layout we can alias)
+        items.sort(key=lambda it: (it[0], it[1]))
+        runs, cur = [], []
+        for it in items:
+            if cur and (cur[-1][0] != it[0] or cur[-1][1] + cur[-1][2] != it[1] or cur[-1][3].dtype != it[3].dtype):
+                runs.append(cur); cur = []
+            cur.append(it)
+        if cur:
+            runs.append(cur)
+        # (addresses differ from rank to rank: the exchange order must not — regions go in the order of their first parameter)
+        order = {id(p): i for i, p in enumerate(self.params)}
+        runs.sort(key=lambda run: min(order[id(it[3])] for it in run))
+        exchange, rest = [], list(missing)
+        for run in runs:
+            nbytes = sum(it[2] for it in run)
+            if nbytes >= self.INPLACE_MIN:
+                g0 = run[0][3].grad
+                n = nbytes // g0.element_size()
+                exchange.append(torch.empty(0, dtype=g0.dtype, device=g0.device).set_(g0.untyped_storage(), g0.storage_offset(), (n,)))
+            else:
+                rest += [it[3] for it in run]
+        if rest:
+            rest.sort(key=lambda p: order[id(p)])
+            layout = tuple((id(p), p.numel()) for p in rest)
+            if getattr(self, "_rest_layout", None) != layout:
+                p0 = rest[0]
+                if any(p.dtype != p0.dtype for p in rest):
+                    raise RuntimeError("GradBuckets.pack: parameters of one network must share a dtype")
+                self._rest_flat = torch.zeros(sum(p.numel() for p in rest), dtype=p0.dtype, device=p0.device)
+                self._rest_views, off = [], 0
+                for p in rest:
+                    self._rest_views.append(self._rest_flat[off:off + p.numel()].view_as(p)); off += p.numel()
+                self._rest_layout = layout
+            have = [(v, p.grad) for v, p in zip(self._rest_views, rest) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
+            none = [v for v, p in zip(self._rest_views, rest) if p.grad is None]
+            if none:
+                torch._foreach_zero_(none)
             if have:
                 torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
-            for v, p in zip(views, plist):
+            for v, p in zip(self._rest_views, rest):
                 p.grad = v
+            exchange.append(self._rest_flat)
+        self._exchange = exchange
 
     def all_reduce(self):
-        """Blocking (stream-ordered) average of every flat bucket over the ranks."""
-        for flat, _, _ in self.buckets:
+        """Blocking (stream-ordered) average over the ranks of what pack() gathered."""
+        for flat in self._exchange:
             if dist.get_backend(self.group) == "nccl":
                 dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
             elif flat.is_cuda:

@@ -61,13 +61,28 @@ def _worker(rank, world, port, out):
     buckets.all_reduce()
     ok &= all(torch.allclose(p.grad, b, atol=1e-6) for p, b in zip(net.parameters(), ref[0]))
     ok &= float(unused.grad.abs().sum()) == 0.0
+    inside = lambda g: any(f.data_ptr() <= g.data_ptr() and g.data_ptr() + g.numel() * 4 <= f.data_ptr() + f.numel() * 4 for f in buckets._exchange)
+    placed = all(inside(p.grad) for p in list(net.parameters()) + [unused])
+    # gradients that already lie back to back in one allocation (the weight arenas' layout) are exchanged where they are
+    plist = list(net.parameters())
+    arena = torch.zeros(sum(p.numel() for p in plist))
+    buckets.zero_grad()
+    buckets.INPLACE_MIN, off = 16, 0
+    local = torch.autograd.grad(net(x).pow(2).mean(), plist)
+    for p, g in zip(plist, local):
+        v = arena[off:off + p.numel()].view_as(p); v.copy_(g); p.grad = v; off += p.numel()
+    buckets.pack()
+    placed &= any(f.data_ptr() == arena.data_ptr() and f.numel() == arena.numel() for f in buckets._exchange)
+    placed &= all(p.grad.data_ptr() >= arena.data_ptr() and p.grad.data_ptr() < arena.data_ptr() + arena.numel() * 4 for p in plist)
+    buckets.all_reduce()
+    ok &= all(torch.allclose(p.grad, b, atol=1e-6) for p, b in zip(plist, ref[0]))
     buckets.manual(False)
     same_params = True
     for p in net.parameters():
         t = p.data.clone()
         dist.broadcast(t, 0)
         same_params &= bool(torch.equal(t, p.data))
-    out[rank] = (ok, same_params, float(unused.grad.abs().sum()), all(p.grad.data_ptr() == v.data_ptr() for (_, pl, vs) in buckets.buckets for p, v in zip(pl, vs)))
+    out[rank] = (ok, same_params, float(unused.grad.abs().sum()), placed)
     dist.destroy_process_group()
 
 
