@@ -24,3 +24,14 @@ ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in win if (r.ge
 gaps = [b[0] - a[1] for a, b in zip(ev, ev[1:])]
 import statistics
 print(f"  busiest queue: median gap {statistics.median(gaps) / 1e3:.2f} us, mean {statistics.mean(gaps) / 1e3:.2f} us, gaps > 20 us: {sum(g > 20000 for g in gaps) / steps:.0f}/step totalling {sum(g for g in gaps if g > 20000) / 1e6 / steps:.3f} ms/step")
+# the kernels of each queue
+import re
+for k in sorted(q, key=lambda k: -q[k][1]):
+    agg = collections.defaultdict(lambda: [0, 0])
+    for r in win:
+        if (r.get("Queue_Id"), r.get("Stream_Id")) == k:
+            name = re.sub(r"^void |\(anonymous namespace\)::", "", r["Kernel_Name"])[:110]
+            agg[name][0] += 1; agg[name][1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    print(f"-- queue {k[0]} stream {k[1]}: top kernels (launches/step, ms/step, avg us)")
+    for name, (n, busy) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:28]:
+        print(f"   {n / steps:6.0f} {busy / 1e6 / steps:7.3f} {busy / 1e3 / n:7.1f}  {name}")
