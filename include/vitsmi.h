@@ -189,8 +189,8 @@ int vits_wgrad_reduce_pending(const vits_wgrad_pending* list, int count, void* s
  * give every entry with splits[i] > 1 a `workspace` of at least splits[i] * (k*c_out*c_in + c_out) floats and pass a `pending`
  * array of `count` entries (pending[i].splits == 0 afterwards: entry i is final), then run vits_wgrad_reduce_pending on it;
  * an entry without workspace / pending runs unsplit.
- * Returns VITS_E_UNSUPPORTED if any entry is not eligible (strided, grouped, dilated beyond the staged halo ...): the caller
- * then issues the per-layer calls. */
+ * Both return VITS_E_UNSUPPORTED if any entry is not eligible (strided, grouped, dilated beyond the staged halo ...): the caller
+ * then issues the per-layer calls (the plan call is also the host-side eligibility test: nothing is launched by it). */
 int vits_conv1d_cl_wgrad_batch_plan(const vits_wgrad_desc* descs, int count, int* splits_out);
 int vits_conv1d_cl_wgrad_batch(const vits_wgrad_desc* descs, int count, void* stream, vits_wgrad_pending* pending);
 

@@ -325,6 +325,8 @@ void plan_group(const vits_wgrad_desc* g, int m, int kt, int* S) {
 // caller gives every entry with splits > 1 a workspace of splits * (k*c_out*c_in + c_out) floats.
 extern "C" int vits_conv1d_cl_wgrad_batch_plan(const vits_wgrad_desc* descs, int count, int* splits_out) {
   if (!descs || count <= 0 || count > 1024 || !splits_out) return VITS_E_BADARG;
+  for (int i = 0; i < count; ++i)
+    if (!eligible(descs[i]) || descs[i].dtype != descs[0].dtype) return VITS_E_UNSUPPORTED;      // (as the launch itself would)
   bool done[1024] = {false};
   for (int i0 = 0; i0 < count; ++i0) {
     if (done[i0]) continue;

@@ -654,6 +654,7 @@ class DeferredReductions:
 
     def __init__(self, device):
         self.device, self.pending, self.stream = device, [], None
+        self.batch = []                # weight-gradient launches handed in by add_wgrad(): run as one batched launch at the flush
 
     def _key(self):
         return (self.device, torch.cuda.current_stream(self.device).cuda_stream)
@@ -699,8 +700,27 @@ class DeferredReductions:
         self.pending.append(pend)
         st[2] += 1
 
+    def add_wgrad(self, entry):
+        """Defers a whole weight-gradient LAUNCH (an entry of conv1d_cl_wgrad_batch: x, dy, k, out, ...; the tensors are kept
+        alive here) to the flush, where all of them run as one batched launch — the single convolutions of the text encoder,
+        the duration predictor and the flows' projections are ~100 launches of one or two workgroup rounds each otherwise.
+        Returns False if the entry is not eligible for the batched kernel (the caller then launches it itself)."""
+        if not wgrad_batch_eligible(entry):
+            return False
+        self._st()                                     # (stream check)
+        if self.stream is None:
+            self.stream = self._key()[1]
+        self.batch.append(entry)
+        return True
+
     def flush(self):
+        if self.batch:
+            batch, self.batch = self.batch, []
+            if not conv1d_cl_wgrad_batch(batch, defer=self):
+                raise RuntimeError("DeferredReductions: a deferred weight-gradient batch was refused")      # (eligibility was tested at add_wgrad)
         if not self.pending:
+            if not self.batch:
+                self.stream = None
             return
         import ctypes
         st = self._st()
@@ -776,16 +796,8 @@ def conv1d_cl_wgrad_raw(x, dy, k, lengths=None, dil=1, pad=0, stride=1, in_slope
     return out
 
 
-def conv1d_cl_wgrad_batch(entries, defer=None):
-    """The weight (+ bias) gradients of a group of stride-1 "same" convolutions in one launch per taps-per-group class
-    (vits_conv1d_cl_wgrad_batch, csrc/conv1d_wgrad_batch.hip).  entries: dicts with x [b,t,c_in], dy [b,t,c_out], k, out
-    (fp32 [k,c_out,c_in], written), and optionally dbias (fp32 [c_out]), lengths, dil, pad, flags, in_slope.  With enough tiles in the
-    group nothing but `out` is written; a small group splits the reduction into slabs, which need `defer` (a
-    DeferredReductions collector: the caller flushes it).  Returns False when an entry is not eligible (nothing was launched)."""
-    import ctypes
-    L = _lib.lib()
-    n = len(entries)
-    descs = (_lib.WgradDesc * n)()
+def _wgrad_batch_descs(entries):
+    descs = (_lib.WgradDesc * len(entries))()
     for d, e in zip(descs, entries):
         x, dy, out = e["x"], e["dy"], e["out"]
         _lib.require_cuda(x, dy, out)
@@ -801,17 +813,47 @@ def conv1d_cl_wgrad_batch(entries, defer=None):
         d.x, d.dy, d.dw = x.data_ptr(), dy.data_ptr(), out.data_ptr()
         d.lengths = None if lengths is None else lengths.data_ptr()
         d.dbias = None if db is None else db.data_ptr()
-    # slabs only for entries whose reduction the launcher will split (long reductions over few tiles)
+    return descs
+
+
+def wgrad_batch_eligible(entry):
+    """Whether conv1d_cl_wgrad_batch takes this entry (host-side test, nothing is launched)."""
+    import ctypes
+    x, dy = entry["x"], entry["dy"]
+    if x.dim() != 3 or dy.dim() != 3 or x.stride(2) != 1 or dy.stride(2) != 1 or tuple(dy.shape[:2]) != tuple(x.shape[:2]) or x.dtype != dy.dtype:
+        return False
+    d, s = _wgrad_batch_descs([entry]), (ctypes.c_int * 1)()
+    return _lib.lib().vits_conv1d_cl_wgrad_batch_plan(ctypes.addressof(d), 1, ctypes.addressof(s)) == 0
+
+
+def conv1d_cl_wgrad_batch(entries, defer=None):
+    """The weight (+ bias) gradients of a group of stride-1 "same" convolutions in one launch per taps-per-group class
+    (vits_conv1d_cl_wgrad_batch, csrc/conv1d_wgrad_batch.hip).  entries: dicts with x [b,t,c_in], dy [b,t,c_out], k, out
+    (fp32 [k,c_out,c_in], written), and optionally dbias (fp32 [c_out]), lengths, dil, pad, flags, in_slope.  With enough tiles in the
+    group nothing but `out` is written; a small group splits the reduction into slabs, which need `defer` (a
+    DeferredReductions collector: the caller flushes it).  Returns False when an entry is not eligible (nothing was launched)."""
+    import ctypes
+    L = _lib.lib()
+    n = len(entries)
+    descs = _wgrad_batch_descs(entries)
+    # slabs only for entries whose reduction the launcher will split (long reductions over few tiles): ONE allocation for the
+    # whole batch, carved up here (several allocations before the launch could be recycled by an early flush in between)
     pend = None
     if defer is not None:
         splits = (ctypes.c_int * n)()
-        _lib.check(L.vits_conv1d_cl_wgrad_batch_plan(ctypes.addressof(descs), n, ctypes.addressof(splits)), "vits_conv1d_cl_wgrad_batch_plan")
-        for d, S in zip(descs, splits):
-            if S > 1:
-                ws = defer.alloc(S * (d.k * d.c_out * d.c_in + (d.c_out if d.dbias else 0)) * 4)
-                if ws is not None:
-                    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
-                    pend = pend or (_lib.WgradPending * n)()
+        rc = L.vits_conv1d_cl_wgrad_batch_plan(ctypes.addressof(descs), n, ctypes.addressof(splits))
+        if rc == _lib.E_UNSUPPORTED:
+            return False
+        _lib.check(rc, "vits_conv1d_cl_wgrad_batch_plan")
+        need = [(((S * (d.k * d.c_out * d.c_in + (d.c_out if d.dbias else 0)) * 4) + 255) & ~255) if S > 1 else 0 for d, S in zip(descs, splits)]
+        ws = defer.alloc(sum(need)) if sum(need) else None
+        if ws is not None:
+            off = 0
+            for d, nb in zip(descs, need):
+                if nb:
+                    d.workspace, d.workspace_bytes = ws.data_ptr() + off, nb
+                    off += nb
+            pend = (_lib.WgradPending * n)()
     e0 = _lib.timer.start("vits_conv1d_cl_wgrad")
     rc = L.vits_conv1d_cl_wgrad_batch(ctypes.addressof(descs), n, _lib.stream_ptr(), None if pend is None else ctypes.addressof(pend))
     if rc == _lib.E_UNSUPPORTED:

@@ -166,7 +166,7 @@ class WeightArena:
             return
         cur = torch.cuda.current_stream(self.w_fwd.device)
         for key, (d, stream) in list(self.__dict__.get("_defers", {}).items()):
-            if not d.pending:
+            if not d.pending and not d.batch:
                 continue
             if key == cur.cuda_stream:
                 d.flush()

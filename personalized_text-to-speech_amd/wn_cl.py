@@ -84,9 +84,16 @@ class ConvCLFn(torch.autograd.Function):
                     db = ctx.bias_slot[0].db_views[ctx.bias_slot[1]]
                 elif not deferred:
                     db = torch.empty(dy.size(2), dtype=torch.float32, device=dy.device)
-            dw = K.conv1d_cl_wgrad_raw(xd, dy, k, lengths=ctx.lengths, dil=dil, pad=pad, stride=stride, in_slope=in_slope,
-                                       flags=K.CONV_MASK_IN if mask_in else 0, out=dw_out, dbias=db, groups=ctx.groups,
-                                       defer=R.defer if deferred else None)
+            # inside an arena the whole launch is deferred to the arena's flush and batched with the other single convolutions
+            # of its stream (stride-1 "same" convolutions; the rest launch here, only their second stage deferred)
+            if deferred and stride == 1 and ctx.groups == 1 and R.defer.add_wgrad(
+                    dict(x=xd, dy=dy, k=k, out=dw_out, dbias=db, lengths=ctx.lengths, dil=dil, pad=pad, in_slope=in_slope,
+                         flags=K.CONV_MASK_IN if mask_in else 0)):
+                dw = dw_out
+            else:
+                dw = K.conv1d_cl_wgrad_raw(xd, dy, k, lengths=ctx.lengths, dil=dil, pad=pad, stride=stride, in_slope=in_slope,
+                                           flags=K.CONV_MASK_IN if mask_in else 0, out=dw_out, dbias=db, groups=ctx.groups,
+                                           defer=R.defer if deferred else None)
         if want_db and db is None:
             db = K.colsum(dy)
         dx = None
