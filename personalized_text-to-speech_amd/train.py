@@ -256,7 +256,11 @@ class FineTuner:
         replay depends on from the previous one).  Returns the replayed scalars."""
         assert self._graph is not None
         if rtol is None:
-            rtol = 1e-5
+            # Three or more ranks: the captured step all-reduces the arenas' gradient buffers in place while the eager step
+            # reduces 64 MiB buckets — other offsets, other chunking, so RCCL sums a given element over the ranks in another
+            # order and the updates differ in the last bits (two ranks: a + b either way).  The check then still catches what it
+            # is for (a race or a stale buffer changes a loss in its first digits), not bit equality.
+            rtol = 1e-5 if (not self.buckets_g.active or self.buckets_g.world <= 2) else 2e-3
         ts = self._state_tensors()
         snap = [t.detach().clone() for t in ts]
         rng = torch.cuda.get_rng_state(self.device)
