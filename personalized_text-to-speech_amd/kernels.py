@@ -11,6 +11,8 @@ There is no CPU implementation of the HIP ops: they raise on non-GPU tensors.
 """
 import math
 
+import os
+
 import torch
 from torch.nn import functional as F
 
@@ -676,6 +678,20 @@ class DeferredReductions:
         nbytes = (nbytes + 255) & ~255
         st = self._st()
         early = False
+        # right-size an idle buffer before a backward starts filling it: the high-water mark of the previous backward (on any
+        # stream of this device) says what one backward needs — without this a buffer could stay too small for good when every
+        # overflow happened while something was pending (no growth possible then), and the captured step would take the
+        # unsplit fall-backs while an eager step on a fresh stream (right-sized from the start) split: same math, other rounding
+        if st[2] == 0 and st[1]:
+            # nothing pending on this stream: whatever was handed out before has been reduced, or its launch turned out unsplit
+            # and never used it (an allocation without add()) — such slabs used to stay allocated until the next flush WITH
+            # pending entries, and on a stream where none came (direct calls in tests) the buffer filled up for good
+            st[1], st[4] = 0, 0
+        if st[1] == 0 and st[2] == 0 and not torch.cuda.is_current_stream_capturing():
+            seen = max(v[3] for k, v in DeferredReductions._state.items() if k[0] == self.device)
+            want = min(self.LIMIT, (seen * 5 // 4 + 255) & ~255)
+            if st[0].numel() < want:
+                st[0] = torch.empty(want, dtype=torch.uint8, device=self.device)
         if st[1] + nbytes > st[0].numel():
             run = st[4]
             self.flush()                                  # early flush: the buffer is too small for this backward
@@ -688,6 +704,9 @@ class DeferredReductions:
         st[4] += nbytes
         st[3] = max(st[3], st[4])                         # bytes one backward would need without early flushes
         if st[1] + nbytes > st[0].numel():
+            if os.environ.get("VITS_DEBUG_DEFER"):
+                print(f"[defer] no room: stream {self._key()[1]} want {nbytes >> 10} KiB at {st[1] >> 10} of {st[0].numel() >> 10} KiB, pending {st[2]}, "
+                      f"high-water {st[3] >> 10} KiB, capturing {torch.cuda.is_current_stream_capturing()}", flush=True)
             return None                                   # caller falls back to the immediate form
         view = st[0][st[1]:st[1] + nbytes]
         st[1] += nbytes
