@@ -249,6 +249,20 @@ class KernelTimer:
     def reset(self):
         self.events = {}
 
+    @staticmethod
+    def pair_overhead_ms(n=200):
+        """What an event pair with NOTHING between its two records measures on the current stream (median of n): the part of
+        every sample above that is not kernel time (rocprofv3 times the dispatch itself and does not see it)."""
+        import torch
+        pairs = []
+        for _ in range(n):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); b.record()
+            pairs.append((a, b))
+        torch.cuda.synchronize()
+        ms = sorted(a.elapsed_time(b) for a, b in pairs)
+        return ms[len(ms) // 2]
+
 
 timer = KernelTimer()
 
