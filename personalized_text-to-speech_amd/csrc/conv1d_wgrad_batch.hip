@@ -30,6 +30,8 @@ constexpr int CT = 64;           // channels per tile (co and ci)
 constexpr int kThreads = 256;
 constexpr int kMaxBatch = 20;
 constexpr int XROWS_MAX = 160;   // staged X rows per chunk: TK + (KT - 1) * dil
+constexpr int XROWS_WIDE = 184;  // ... of the all-taps-in-one-pass instances (KT = 7, 11: the decoder's k = 7 / 11 layers at dilation <= 5)
+constexpr int xrows_of(int kt) { return kt > 4 ? XROWS_WIDE : XROWS_MAX; }
 
 struct Entry {
   const void* x; const void* dy; float* dw; float* db; float* partial; const int* lengths;
@@ -64,14 +66,15 @@ __device__ __forceinline__ u32x4 lrelu_vec(u32x4 raw, float slope) {
 }
 
 template <typename T, int KT>
-__global__ __launch_bounds__(kThreads, 2) void wgrad_batch_kernel(Table tab) {
+__global__ __launch_bounds__(kThreads, (KT > 8 ? 1 : 2)) void wgrad_batch_kernel(Table tab) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int ES = sizeof(T);
   constexpr int V = 16 / ES;
   constexpr int PITCH = Pitch<T>::value;
   constexpr int VPR = CT / V;                         // 16-byte vectors per tile row
   constexpr int DV = TK * VPR / kThreads;             // dY vectors per thread per chunk (4 bf16 / 8 f32)
-  constexpr int XV = (XROWS_MAX * VPR + kThreads - 1) / kThreads;   // X vectors per thread per chunk (5 / 10)
+  constexpr int XR = xrows_of(KT);
+  constexpr int XV = (XR * VPR + kThreads - 1) / kThreads;          // X vectors per thread per chunk (5 or 6 / 10)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wi = wave >> 1, wj = wave & 1;
   const int r = lane & 31, h = lane >> 5;
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_batch_kernel(Table tab) {
 #pragma unroll
     for (int i = 0; i < XV; ++i) {
       const int idx = tid + i * kThreads;
-      if (idx < XROWS_MAX * VPR) *reinterpret_cast<u32x4*>(ldsX + (idx / VPR) * PITCH + (idx % VPR) * 16) = lrelu ? lrelu_vec<T>(x[i], a.in_slope) : x[i];
+      if (idx < XR * VPR) *reinterpret_cast<u32x4*>(ldsX + (idx / VPR) * PITCH + (idx % VPR) * 16) = lrelu ? lrelu_vec<T>(x[i], a.in_slope) : x[i];
     }
   };
 
@@ -260,12 +263,20 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_batch_kernel(Table tab) {
   }
 }
 
-int taps_per_group(int k) { return k <= 4 ? k : (k <= 8 ? (k + 1) / 2 : 4); }
+// Taps per workgroup.  k = 7 and k = 11 in bf16 (the decoder's resblocks) take all taps in ONE pass when their halo fits the
+// wide staging buffer: with 4 taps per group such a layer was 2 / 3 tap groups, each re-reading x and dy (time_shapes: the
+// decoder's batch ran at 0.93 TB/s algorithmic; A/B on one box, whole step: 20.96-21.03 against 21.32-21.37 ms).  KT = 11 keeps
+// 176 accumulator registers: one workgroup per CU.  The same for k = 5 (the WaveNet layers, 2 groups) measured neutral: not done.
+int taps_per_group(const vits_wgrad_desc& d) {
+  const int k = d.k;
+  if ((k == 7 || k == 11) && d.dtype == VITS_DT_BF16 && TK + (k - 1) * d.dil <= xrows_of(k)) return k;
+  return k <= 4 ? k : (k <= 8 ? (k + 1) / 2 : 4);
+}
 
 template <typename T, int KT>
 int launch(const Table& tab, int blocks, hipStream_t s) {
   constexpr int PITCH = Pitch<T>::value;
-  const size_t lds = (size_t)(TK + XROWS_MAX) * PITCH;
+  const size_t lds = (size_t)(TK + xrows_of(KT)) * PITCH;
   auto kern = wgrad_batch_kernel<T, KT>;
   { const hipError_t e = vits::ensure_max_dynamic_lds(reinterpret_cast<const void*>(kern)); if (e != hipSuccess) return vits::note_hip_error(e, "vits_conv1d_cl_wgrad_batch/attr"); }
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(kThreads), lds, s, tab);
@@ -278,6 +289,8 @@ int dispatch(const Table& tab, int kt, int blocks, hipStream_t s) {
     case 1: return launch<T, 1>(tab, blocks, s);
     case 2: return launch<T, 2>(tab, blocks, s);
     case 3: return launch<T, 3>(tab, blocks, s);
+    case 7: if constexpr (sizeof(T) == 2) return launch<T, 7>(tab, blocks, s); else return VITS_E_UNSUPPORTED;     // (bf16 only, see taps_per_group)
+    case 11: if constexpr (sizeof(T) == 2) return launch<T, 11>(tab, blocks, s); else return VITS_E_UNSUPPORTED;
     default: return launch<T, 4>(tab, blocks, s);
   }
 }
@@ -286,7 +299,7 @@ bool eligible(const vits_wgrad_desc& d) {
   if (!d.x || !d.dy || !d.dw || d.b <= 0 || d.t <= 0 || d.c_in <= 0 || d.c_out <= 0 || d.k <= 0 || d.dil <= 0 || d.pad < 0) return false;
   if ((d.stride > 1) || d.groups > 1 || (d.flags & VITS_CONV_FLAT)) return false;
   if (d.t + 2 * d.pad - d.dil * (d.k - 1) != d.t) return false;                   // "same" convolutions only: t_out == t
-  if (TK + (taps_per_group(d.k) - 1) * d.dil > XROWS_MAX) return false;
+  { const int kt = taps_per_group(d); if (TK + (kt - 1) * d.dil > xrows_of(kt)) return false; }
   const int vec = d.dtype == VITS_DT_BF16 ? 8 : (d.dtype == VITS_DT_F32 ? 4 : 0);
   if (vec == 0) return false;
   const int ldx = d.ldx > 0 ? d.ldx : d.c_in, lddy = d.lddy > 0 ? d.lddy : d.c_out;
@@ -330,10 +343,10 @@ extern "C" int vits_conv1d_cl_wgrad_batch_plan(const vits_wgrad_desc* descs, int
   bool done[1024] = {false};
   for (int i0 = 0; i0 < count; ++i0) {
     if (done[i0]) continue;
-    const int kt = taps_per_group(descs[i0].k);
+    const int kt = taps_per_group(descs[i0]);
     int sel[kMaxBatch], m = 0;
     for (int i = i0; i < count && m < kMaxBatch; ++i)
-      if (!done[i] && taps_per_group(descs[i].k) == kt) { sel[m++] = i; done[i] = true; }
+      if (!done[i] && taps_per_group(descs[i]) == kt) { sel[m++] = i; done[i] = true; }
     vits_wgrad_desc grp[kMaxBatch];
     int S[kMaxBatch];
     for (int j = 0; j < m; ++j) grp[j] = descs[sel[j]];
@@ -356,10 +369,10 @@ extern "C" int vits_conv1d_cl_wgrad_batch(const vits_wgrad_desc* descs, int coun
   if (count > 1024) return VITS_E_UNSUPPORTED;
   for (int i0 = 0; i0 < count; ++i0) {
     if (done[i0]) continue;
-    const int kt = taps_per_group(descs[i0].k);
+    const int kt = taps_per_group(descs[i0]);
     int sel[kMaxBatch], m = 0;
     for (int i = i0; i < count && m < kMaxBatch; ++i)
-      if (!done[i] && taps_per_group(descs[i].k) == kt) { sel[m++] = i; done[i] = true; }
+      if (!done[i] && taps_per_group(descs[i]) == kt) { sel[m++] = i; done[i] = true; }
     vits_wgrad_desc grp[kMaxBatch];
     for (int j = 0; j < m; ++j) grp[j] = descs[sel[j]];
     int S[kMaxBatch];
