@@ -179,7 +179,21 @@ def bench_infer(args, P, cfgs, device):
                             parallelism="dp1", execution="eager launches"), roofline=roof)
 
 
+def emit(line):
+    """The ONE line of the contract, on the process's real stdout."""
+    os.write(_REAL_STDOUT, (json.dumps(line) + "\n").encode())
+
+
+_REAL_STDOUT = 1
+
+
 def main():
+    # Native libraries print to stdout too (RCCL's version banner at the first collective): everything except the JSON line
+    # goes to stderr, the line itself to the descriptor stdout had when the process started.
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--branches", default=None, help="comma list of side-stream branches (enc_p,dp,mel); default: all")
@@ -225,7 +239,7 @@ def main():
     if args.workload == "C4":
         if world != 1:
             raise SystemExit("workload C4 (inference) runs as independent replicas: launch it with --gpus 1 per GPU")
-        print(json.dumps(bench_infer(args, P, cfgs, device)))
+        emit(bench_infer(args, P, cfgs, device))
         return
     cfg_name, batch_size, t_y_range = cfgs.WORKLOADS[args.workload]
     hps = cfgs.get(cfg_name)
@@ -403,7 +417,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfgs)
             line["cpu_baseline"]["alignment_dp"]["gpu"] = alignment_gpu(P, device)
-        print(json.dumps(line))
+        emit(line)
     if world > 1 or (dist.is_available() and dist.is_initialized()):
         dist.destroy_process_group()
 
