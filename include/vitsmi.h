@@ -142,6 +142,14 @@ typedef struct vits_conv_desc {
 
 int vits_conv1d_cl(const vits_conv_desc* desc, void* stream);
 
+/* `count` (2..8) independent convolutions in ONE launch — the same layer of the five period discriminators
+ * (models.py:299-335: same channels, taps and stride; other row counts, other weights), forward or data gradient: alone each is
+ * one partly filled round of workgroups, side by side they fill each other's tails and share one launch boundary.  All or
+ * nothing: VITS_E_UNSUPPORTED (nothing launched) unless every descriptor is a launch vits_conv1d_cl would give to the same
+ * instance of its deep-prefetch kernel (bf16, c_in >= 128, c_out >= 96, k >= 2, plain epilogues) — the caller then issues
+ * `count` vits_conv1d_cl calls.  Results are bitwise those of the separate calls. */
+int vits_conv1d_cl_multi(const vits_conv_desc* descs, int count, void* stream);
+
 /* Weight gradient of vits_conv1d_cl (same x, lengths, in_slope, MASK flags as the forward call):
  *   dw[tap][co][ci] (+)= sum_{b,t} dy[b][t][co] * lrelu_{in_slope}(x[b][t + tap*dil - pad][ci])
  * Replaces the weight half of autograd's conv1d backward for the layers listed above.

@@ -10,7 +10,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvitsmi.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 c_int = ctypes.c_int
 c_void_p = ctypes.c_void_p
@@ -51,6 +51,7 @@ SIGNATURES = {
     "vits_conv1d_cl_wgrad_batch_plan": (c_int, [c_void_p, c_int, c_void_p]),
     "vits_conv1d_cl_wgrad_batch": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "vits_conv1d_cl": (c_int, [c_void_p, c_void_p]),
+    "vits_conv1d_cl_multi": (c_int, [c_void_p, c_int, c_void_p]),
     "vits_wn_layer_fwd": (c_int, [c_void_p, c_void_p]),
     "vits_wn_layer_bwd": (c_int, [c_void_p, c_void_p]),
     "vits_wn_pack_bytes": (c_size_t, [c_int] * 6),

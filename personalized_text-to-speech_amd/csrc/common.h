@@ -23,6 +23,8 @@ __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; 
 int conv1d_flat_dispatch(const vits_conv_desc& d, int t_out, hipStream_t s);
 // csrc/conv1d_ring.hip: LDS-DMA ring variant (bf16, c_in % 64 == 0, k >= 2); VITS_E_UNSUPPORTED = take another kernel
 int conv1d_ring_dispatch(const vits_conv_desc& d, int t_out, hipStream_t s);
+// ... `count` problems of one kernel instance side by side in ONE launch (all or nothing)
+int conv1d_ring_multi_dispatch(const vits_conv_desc* d, const int* t_out, int count, hipStream_t s);
 
 // csrc/conv1d_wgrad_ring.hip: large-tile, deep-prefetch weight-gradient kernel (bf16); plan.TC == 0: not eligible
 struct WgradRingPlan { int TC, TK, KT, XR, S; };

@@ -514,14 +514,13 @@ bool small_m_applies(const vits_conv_desc& d, int t_out) {
 
 }  // namespace
 
-extern "C" int vits_conv1d_cl(const vits_conv_desc* desc, void* stream) {
-  if (!desc) return VITS_E_BADARG;
-  vits_conv_desc d = *desc;
+namespace {
+// Validation and defaults shared by the entry points: VITS_OK and the output length, or the error to return.
+int normalize_desc(vits_conv_desc& d, int& t_out) {
   if (!d.x || !d.w || !d.y || d.b <= 0 || d.t <= 0 || d.c_in <= 0 || d.c_out <= 0 || d.k <= 0 || d.dil <= 0 || d.pad < 0)
     return VITS_E_BADARG;
   if (d.stride <= 0) d.stride = 1;
   const int in_div = d.in_div > 1 ? d.in_div : 1;
-  int t_out;
   if (in_div > 1) {                         // data gradient of a strided convolution: the caller states the output length
     if (d.stride != 1 || d.t_out_override <= 0) return VITS_E_BADARG;
     t_out = d.t_out_override;
@@ -541,10 +540,44 @@ extern "C" int vits_conv1d_cl(const vits_conv_desc* desc, void* stream) {
   if (d.w_batch_stride < 0) return VITS_E_BADARG;
   if (d.ldy <= 0) d.ldy = (gate || res_skip) ? d.gate_h : (gate_bwd ? 2 * d.gate_h : d.c_out);
   if (d.ldy2 <= 0) d.ldy2 = res_skip ? d.gate_h : d.c_out;
-  hipStream_t s = static_cast<hipStream_t>(stream);
   const int vec = d.dtype == VITS_DT_BF16 ? 8 : (d.dtype == VITS_DT_F32 ? 4 : 0);
   if (vec == 0) return VITS_E_UNSUPPORTED;
   if (d.c_in % vec != 0 || d.ldx % vec != 0 || d.ldw % vec != 0 || d.w_batch_stride % vec != 0) return VITS_E_UNSUPPORTED;
+  if (d.groups > 1 && (d.c_out % d.groups != 0 || d.c_in % d.groups != 0)) return VITS_E_BADARG;
+  return VITS_OK;
+}
+
+// the launches the deep-prefetch ring kernel is tried for (csrc/conv1d_ring.hip decides the rest)
+bool ring_candidate(const vits_conv_desc& d, int t_out) {
+  const bool plain = !(d.flags & (VITS_CONV_GATE | VITS_CONV_GATE_BWD | VITS_CONV_RES_SKIP)) && d.w_batch_stride == 0 && d.y2 == nullptr;
+  return d.dtype == VITS_DT_BF16 && plain && d.groups <= 1 && d.k >= 2 && d.c_in >= 128 && d.c_out >= 96 && !small_m_applies(d, t_out) &&
+         !(d.flags & VITS_CONV_FLAT);
+}
+}  // namespace
+
+extern "C" int vits_conv1d_cl_multi(const vits_conv_desc* descs, int count, void* stream) {
+  if (!descs || count <= 0) return VITS_E_BADARG;
+  if (count < 2 || count > 8) return VITS_E_UNSUPPORTED;
+  vits_conv_desc d[8];
+  int t_out[8];
+  for (int i = 0; i < count; ++i) {
+    d[i] = descs[i];
+    const int rc = normalize_desc(d[i], t_out[i]);
+    if (rc != VITS_OK) return rc;
+    if (!ring_candidate(d[i], t_out[i])) return VITS_E_UNSUPPORTED;
+  }
+  return vits::conv1d_ring_multi_dispatch(d, t_out, count, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int vits_conv1d_cl(const vits_conv_desc* desc, void* stream) {
+  if (!desc) return VITS_E_BADARG;
+  vits_conv_desc d = *desc;
+  int t_out;
+  { const int rc = normalize_desc(d, t_out); if (rc != VITS_OK) return rc; }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int in_div = d.in_div > 1 ? d.in_div : 1;
+  const bool gate = (d.flags & VITS_CONV_GATE) != 0, gate_bwd = (d.flags & VITS_CONV_GATE_BWD) != 0;
+  const bool res_skip = (d.flags & VITS_CONV_RES_SKIP) != 0;
   if (small_m_applies(d, t_out)) {
     hipLaunchKernelGGL(small_m_kernel, dim3(d.c_out), dim3(256), 0, s, static_cast<const __bf16*>(d.x), static_cast<const __bf16*>(d.w),
                        d.bias, static_cast<__bf16*>(d.y), d.b * t_out, d.c_out, d.c_in, d.ldx, d.ldw, d.ldy, d.out_scale);
@@ -553,7 +586,6 @@ extern "C" int vits_conv1d_cl(const vits_conv_desc* desc, void* stream) {
   // flat-row kernel: strided / divided launches, and short sequences spread over many items (most of a per-item
   // time tile would be empty).  It has no gate epilogues and no per-item operands.
   const bool flat_ok = !gate && !gate_bwd && !res_skip && d.w_batch_stride == 0 && d.y2 == nullptr;
-  if (d.groups > 1 && (d.c_out % d.groups != 0 || d.c_in % d.groups != 0)) return VITS_E_BADARG;
   const bool must_flat = in_div > 1 || (d.flags & VITS_CONV_FLAT) != 0 || d.groups > 1;
   if (must_flat && !flat_ok) return VITS_E_UNSUPPORTED;
   const bool auto_flat = true;

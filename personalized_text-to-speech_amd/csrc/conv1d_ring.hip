@@ -45,8 +45,9 @@ struct RingArgs {
 
 __device__ __forceinline__ float to_f(__bf16 v) { return (float)v; }
 
+// The workgroup `id` of `nwg` of one problem (the kernels below: one problem per launch, or several side by side).
 template <int BM, int XIM>
-__global__ __launch_bounds__(kThreads) void conv1d_ring_kernel(RingArgs args) {
+__device__ __forceinline__ void ring_body(const RingArgs& args, const int nwg, const int id) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const vits_conv_desc& a = args.d;
   constexpr int RI = BM / 64;                         // 32-row blocks per wave (wave tile = BM/2 rows x 64 columns)
@@ -56,7 +57,6 @@ __global__ __launch_bounds__(kThreads) void conv1d_ring_kernel(RingArgs args) {
   const int M = args.M, dil = a.dil;
 
   // ---- tile of this workgroup (XCD-aware: ids that share an XCD walk the row tiles of one column tile)
-  const int nwg = gridDim.x, id = blockIdx.x;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = id & 7;
   const int nid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
   const int col_tile = nid / args.n_row_tiles, row_all = nid - col_tile * args.n_row_tiles;
@@ -331,6 +331,39 @@ __global__ __launch_bounds__(kThreads) void conv1d_ring_kernel(RingArgs args) {
 }
 
 template <int BM, int XIM>
+__global__ __launch_bounds__(kThreads) void conv1d_ring_kernel(RingArgs args) {
+  ring_body<BM, XIM>(args, gridDim.x, blockIdx.x);
+}
+
+// Several independent problems of the same kernel instance in ONE launch (the same layer of the five period discriminators:
+// same channels and taps, other row counts and other weights).  A discriminator layer alone is 208-304 workgroups on 256 CUs —
+// one round at 81 % of the CUs, or two rounds with the second a fifth full; side by side the problems fill each other's tails,
+// and four of five launch boundaries go.  Every problem's workgroup ids start at a multiple of 8, so that blockIdx & 7 — the XCD —
+// is also its local id & 7 and the XCD-aware tile walk of the body holds; the padding workgroups exit at once.
+constexpr int kMaxMulti = 8;
+struct MultiArgs { RingArgs a[kMaxMulti]; int start[kMaxMulti + 1]; int n; };
+
+template <int BM, int XIM>
+__global__ __launch_bounds__(kThreads) void conv1d_ring_multi_kernel(MultiArgs m) {
+  int p = 0;
+#pragma unroll 1
+  for (int i = 1; i < m.n; ++i) if ((int)blockIdx.x >= m.start[i]) p = i;
+  const RingArgs& args = m.a[p];
+  const int id = blockIdx.x - m.start[p], nwg = args.n_row_tiles * args.n_col_tiles;
+  if (id >= nwg) return;                                  // (uniform over the workgroup)
+  ring_body<BM, XIM>(args, nwg, id);
+}
+
+template <int BM, int XIM>
+int launch_ring_multi(const MultiArgs& m, size_t lds, hipStream_t s) {
+  auto kern = conv1d_ring_multi_kernel<BM, XIM>;
+  hipError_t e = vits::ensure_max_dynamic_lds(reinterpret_cast<const void*>(kern));
+  if (e != hipSuccess) return vits::note_hip_error(e, "vits_conv1d_cl_multi(ring)/attr");
+  hipLaunchKernelGGL(kern, dim3(m.start[m.n]), dim3(kThreads), lds, s, m);
+  return vits::check_launch("vits_conv1d_cl_multi(ring)");
+}
+
+template <int BM, int XIM>
 int launch_ring(const RingArgs& args, size_t lds, hipStream_t s) {
   auto kern = conv1d_ring_kernel<BM, XIM>;
   hipError_t e = vits::ensure_max_dynamic_lds(reinterpret_cast<const void*>(kern));
@@ -341,11 +374,13 @@ int launch_ring(const RingArgs& args, size_t lds, hipStream_t s) {
 
 }  // namespace
 
-namespace vits {
-
 // Called by vits_conv1d_cl (d validated and defaulted, bf16).  Returns VITS_E_UNSUPPORTED when the shape is outside what this
 // kernel handles; the caller then takes the other kernels.
-int conv1d_ring_dispatch(const vits_conv_desc& d, int t_out, hipStream_t s) {
+namespace {
+struct RingPlan { RingArgs args; int BM; bool wide; size_t lds; };
+
+// VITS_OK and the plan, or VITS_E_UNSUPPORTED when the shape is outside what this kernel handles.
+int ring_plan(const vits_conv_desc& d, int t_out, RingPlan* out) {
   if (d.dtype != VITS_DT_BF16 || d.c_in % 64 != 0 || d.k < 2 || d.groups > 1 || d.w_batch_stride != 0) return VITS_E_UNSUPPORTED;
   const int P = d.in_div > 1 ? d.in_div : 1;
   // data gradient of a strided convolution: dil 1, every phase keeps at least one tap, no length masks (the two grids differ)
@@ -362,6 +397,7 @@ int conv1d_ring_dispatch(const vits_conv_desc& d, int t_out, hipStream_t s) {
   if (M * P >= (1l << 30)) return VITS_E_UNSUPPORTED;
   const int n_col = vits::ceil_div(d.c_out, BN);
   // 128-row tiles when they still fill the chip, else 64-row tiles; too few tiles: the other kernels' smaller tiles win
+  // (threshold 200 re-measured in round 3 against 120 / 260 / 520 in the whole step: each of them +0.1 to +0.3 ms)
   int BM = ((M + 127) / 128) * n_col * P >= 200 ? 128 : 64;
   if (((M + 63) / 64) * n_col * P < 100) return VITS_E_UNSUPPORTED;
   const int halo = P > 1 ? (d.k + P - 1) / P : (d.k - 1) * d.dil + 1;      // (phases: the longest tap subset)
@@ -376,10 +412,47 @@ int conv1d_ring_dispatch(const vits_conv_desc& d, int t_out, hipStream_t s) {
   auto fits = [&](int xr) { return (size_t)2 * xr * ROWB + (size_t)2 * WSTAGE <= (size_t)vits::kLdsBytesMax && xr <= 32 * XI_MAX; };
   if (!fits(XR) && BM == 128) { BM = 64; XR = xrows(BM); }
   if (!fits(XR)) return VITS_E_UNSUPPORTED;
-  RingArgs args{d, t_rows, (int)M, XR, P * (int)((M + BM - 1) / BM), n_col, P, t_out};
-  const size_t lds = (size_t)2 * XR * ROWB + (size_t)2 * WSTAGE;
-  if (XR <= 32 * 6) return BM == 128 ? launch_ring<128, 6>(args, lds, s) : launch_ring<64, 6>(args, lds, s);
-  return BM == 128 ? launch_ring<128, 14>(args, lds, s) : launch_ring<64, 14>(args, lds, s);
+  out->args = RingArgs{d, t_rows, (int)M, XR, P * (int)((M + BM - 1) / BM), n_col, P, t_out};
+  out->BM = BM;
+  out->wide = XR > 32 * 6;
+  out->lds = (size_t)2 * XR * ROWB + (size_t)2 * WSTAGE;
+  return VITS_OK;
+}
+}  // namespace
+
+namespace vits {
+
+int conv1d_ring_dispatch(const vits_conv_desc& d, int t_out, hipStream_t s) {
+  RingPlan p;
+  const int rc = ring_plan(d, t_out, &p);
+  if (rc != VITS_OK) return rc;
+  if (!p.wide) return p.BM == 128 ? launch_ring<128, 6>(p.args, p.lds, s) : launch_ring<64, 6>(p.args, p.lds, s);
+  return p.BM == 128 ? launch_ring<128, 14>(p.args, p.lds, s) : launch_ring<64, 14>(p.args, p.lds, s);
+}
+
+// `count` problems (validated and defaulted by the caller like conv1d_ring_dispatch's) in one launch: only when every one of
+// them is this kernel's and they agree on the instance; else VITS_E_UNSUPPORTED and nothing is launched.
+int conv1d_ring_multi_dispatch(const vits_conv_desc* d, const int* t_out, int count, hipStream_t s) {
+  if (count < 2 || count > kMaxMulti) return VITS_E_UNSUPPORTED;
+  MultiArgs m;
+  RingPlan p0;
+  size_t lds = 0;
+  int start = 0;
+  for (int i = 0; i < count; ++i) {
+    RingPlan p;
+    const int rc = ring_plan(d[i], t_out[i], &p);
+    if (rc != VITS_OK) return rc;
+    if (i == 0) p0 = p;
+    else if (p.BM != p0.BM || p.wide != p0.wide) return VITS_E_UNSUPPORTED;
+    lds = p.lds > lds ? p.lds : lds;
+    m.a[i] = p.args;
+    m.start[i] = start;
+    start += (p.args.n_row_tiles * p.args.n_col_tiles + 7) & ~7;
+  }
+  m.start[count] = start;
+  m.n = count;
+  if (!p0.wide) return p0.BM == 128 ? launch_ring_multi<128, 6>(m, lds, s) : launch_ring_multi<64, 6>(m, lds, s);
+  return p0.BM == 128 ? launch_ring_multi<128, 14>(m, lds, s) : launch_ring_multi<64, 14>(m, lds, s);
 }
 
 }  // namespace vits

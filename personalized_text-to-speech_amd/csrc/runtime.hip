@@ -13,5 +13,5 @@ int note_hip_error(hipError_t e, const char* where) {
 }
 }  // namespace vits
 
-extern "C" int vits_abi_version(void) { return 15; }
+extern "C" int vits_abi_version(void) { return 16; }
 extern "C" const char* vits_last_error(void) { return g_last_error.c_str(); }

@@ -223,28 +223,37 @@ class DiscFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, plans, groups, dtype, n_lo, x, *wb):
-        C = K.conv1d_cl_raw
         xd = x.detach().float().contiguous()
         R = [WA.resolve(t, dtype) if (t is not None and t.dim() == 3) else None for t in wb]
-        outs, saved, layout = [], [xd], []
-        it = 0
-        for plan, grp in zip(plans, groups):
-            p = plan.period
+        bases, it = [], 0
+        for plan in plans:
+            bases.append(it)
+            it += 2 * (len(plan.mid) + 2)
+        # layer by layer ACROSS the discriminators: the same layer of the five period discriminators is five independent
+        # launches of one kernel instance, each a partly filled round of workgroups — K.conv1d_cl_multi puts them side by side
+        hs_all = []
+        for plan, base in zip(plans, bases):
             k, s1, pad, c1 = plan.first
-            base = it
-            h = first_fwd(xd, R[it].fwd, _f32(wb[it + 1]), p, k, s1, pad, c1, dtype)
-            it += 2
-            hs = [h]
-            for (ci, co, kk, st, pd, _), g in zip(plan.mid, grp):
+            hs_all.append([first_fwd(xd, R[base].fwd, _f32(wb[base + 1]), plan.period, k, s1, pad, c1, dtype)])
+        for j in range(max(len(plan.mid) for plan in plans)):
+            calls, owners = [], []
+            for pi, (plan, grp, base) in enumerate(zip(plans, groups, bases)):
+                if j >= len(plan.mid):
+                    continue
+                (ci, co, kk, st, pd, _), g = plan.mid[j], grp[j]
+                h, iw = hs_all[pi][-1], base + 2 * (j + 1)
                 if grouped_direct_ok(h, ci, co, kk, st, g):
-                    h = grouped_fwd(h, R[it].fwd, _f32(wb[it + 1]), kk, st, pd, g)
+                    hs_all[pi].append(grouped_fwd(h, R[iw].fwd, _f32(wb[iw + 1]), kk, st, pd, g))
                 else:
-                    h = C(h, R[it].fwd, _f32(wb[it + 1]), pad=pd, stride=st, out_slope=SLOPE, groups=g)
-                it += 2
-                hs.append(h)
+                    calls.append((h, R[iw].fwd, dict(bias=_f32(wb[iw + 1]), pad=pd, stride=st, out_slope=SLOPE, groups=g)))
+                    owners.append(pi)
+            for pi, y in zip(owners, _multi(calls)):
+                hs_all[pi].append(y)
+        outs, saved, layout = [], [xd], []
+        for plan, base, hs in zip(plans, bases, hs_all):
+            ip = base + 2 * len(hs)
             pk, ppad, _ = plan.post
-            y8 = post_fwd(h, R[it].fwd, _f32(wb[it + 1]), pk, ppad)
-            it += 2
+            y8 = post_fwd(hs[-1], R[ip].fwd, _f32(wb[ip + 1]), pk, ppad)
             outs += [y8] + hs
             layout.append((base, len(hs)))
             saved += hs
@@ -255,7 +264,7 @@ class DiscFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gout):
-        C, WG = K.conv1d_cl_raw, K.conv1d_cl_wgrad_raw
+        WG = K.conv1d_cl_wgrad_raw
         saved = list(ctx.saved_tensors)
         xd = saved[0]
         n, T = xd.shape
@@ -264,19 +273,17 @@ class DiscFn(torch.autograd.Function):
         grads = [None] * len(R)
         defer = K.DeferredReductions(xd.device)
         dx = torch.empty((n, T), device=xd.device, dtype=torch.float32) if need_x else None
-        wrote_dx = False
-        si, gi = 1, 0
+        cont = lambda t: None if t is None else (t if t.is_contiguous() else t.contiguous())
+        # ---- per discriminator: its saved feature maps, incoming gradients, conv_post
+        st_all, si, gi = [], 1, 0
         for plan, grp, (base, nh) in zip(ctx.plans, ctx.groups, ctx.layout):
             hs = saved[si:si + nh]
             si += nh
             dy8, dhs = gout[gi], list(gout[gi + 1:gi + 1 + nh])
             gi += 1 + nh
-            p = plan.period
-            lo = n_lo * p
+            lo = n_lo * plan.period
             need_w = any(ctx.needs_input_grad[5 + base + 2 * j] for j in range(nh + 1))
             assert not (need_w and n_lo), "weight gradients need the whole batch"
-            cont = lambda t: None if t is None else (t if t.is_contiguous() else t.contiguous())
-            # ---- conv_post
             ip = base + 2 * nh
             pk, ppad, _ = plan.post
             hL = hs[-1]
@@ -290,38 +297,50 @@ class DiscFn(torch.autograd.Function):
                 dcur = post_dgrad(dy8, R[ip].fwd, cont(dhs[-1]), hL, lo, pk, ppad)
             elif dhs[-1] is not None:
                 dcur = K.lrelu_mask_bwd(cont(dhs[-1][lo:]), cont(hL[lo:]), SLOPE)
-            # ---- middle layers, last to first
-            for li in range(nh - 1, 0, -1):
-                ci, co, kk, st, pd, _ = plan.mid[li - 1]
-                g = grp[li - 1]
-                iw = base + 2 * li
-                x_in = hs[li - 1][lo:]
-                dprev = dhs[li - 1]
+            st_all.append(dict(plan=plan, grp=grp, base=base, nh=nh, hs=hs, dhs=dhs, lo=lo, need_w=need_w, dcur=dcur))
+        # ---- middle layers, last to first, layer by layer across the discriminators (see forward)
+        for li in range(max(st["nh"] for st in st_all) - 1, 0, -1):
+            calls, owners = [], []
+            for st in st_all:
+                if li >= st["nh"]:
+                    continue
+                ci, co, kk, sd, pd, _ = st["plan"].mid[li - 1]
+                g, lo = st["grp"][li - 1], st["lo"]
+                iw = st["base"] + 2 * li
+                x_in = st["hs"][li - 1][lo:]
+                dprev, dcur = st["dhs"][li - 1], st["dcur"]
                 if dcur is None:
                     if dprev is not None:
-                        dcur = K.lrelu_mask_bwd(cont(dprev[lo:]), cont(x_in), SLOPE)
+                        st["dcur"] = K.lrelu_mask_bwd(cont(dprev[lo:]), cont(x_in), SLOPE)
                     continue
-                if need_w:
+                direct = grouped_direct_ok(dcur, ci, co, kk, sd, g)
+                if st["need_w"]:
                     db = torch.empty(co, device=xd.device, dtype=torch.float32)
                     dw_out = R[iw].claim_dw(ctx)
-                    grads[iw] = grouped_wgrad(cont(x_in), cont(dcur), kk, st, pd, g, dw_out, db, defer) if grouped_direct_ok(dcur, ci, co, kk, st, g) else None
+                    grads[iw] = grouped_wgrad(cont(x_in), cont(dcur), kk, sd, pd, g, dw_out, db, defer) if direct else None
                     if grads[iw] is None:
-                        grads[iw] = WG(x_in, dcur, kk, pad=pd, stride=st, out=dw_out, dbias=db, groups=g, defer=defer)
+                        grads[iw] = WG(x_in, dcur, kk, pad=pd, stride=sd, out=dw_out, dbias=db, groups=g, defer=defer)
                     grads[iw + 1] = db
-                if grouped_direct_ok(dcur, ci, co, kk, st, g):
-                    dcur = grouped_dgrad(cont(dcur), R[iw].fwd, None if dprev is None else cont(dprev[lo:]), cont(x_in), x_in.size(1), kk, st, pd, g)
+                if direct:
+                    st["dcur"] = grouped_dgrad(cont(dcur), R[iw].fwd, None if dprev is None else cont(dprev[lo:]), cont(x_in), x_in.size(1), kk, sd, pd, g)
                 else:
-                    dcur = C(dcur, WA.bwd_operand(R[iw]), None, res=None if dprev is None else cont(dprev[lo:]), mg_src=x_in, mg_slope=SLOPE,
-                             pad=(kk - 1) - pd, in_div=st, t_out=x_in.size(1) if st != 1 else None, groups=g)
-            # ---- first layer
+                    calls.append((dcur, WA.bwd_operand(R[iw]), dict(res=None if dprev is None else cont(dprev[lo:]), mg_src=x_in, mg_slope=SLOPE,
+                                                                     pad=(kk - 1) - pd, in_div=sd, t_out=x_in.size(1) if sd != 1 else None, groups=g)))
+                    owners.append(st)
+            for st, y in zip(owners, _multi(calls)):
+                st["dcur"] = y
+        # ---- first layers
+        wrote_dx = False
+        for st in st_all:
+            dcur, plan, base = st["dcur"], st["plan"], st["base"]
             if dcur is not None:
                 k, s1, pad, c1 = plan.first
-                if need_w:
+                if st["need_w"]:
                     dw = _dw_buffer(R[base], (k, c1, 8), xd.device, ctx)
-                    grads[base + 1] = first_wgrad(xd, dcur, dw, p, k, s1, pad, c1)
+                    grads[base + 1] = first_wgrad(xd, dcur, dw, plan.period, k, s1, pad, c1)
                     grads[base] = dw
                 if need_x:
-                    first_dgrad(dcur, R[base].fwd, dx, n, n_lo, p, k, s1, pad, c1, accumulate=wrote_dx)
+                    first_dgrad(dcur, R[base].fwd, dx, n, n_lo, plan.period, k, s1, pad, c1, accumulate=wrote_dx)
                     wrote_dx = True
         defer.flush()
         if need_x:
@@ -330,6 +349,23 @@ class DiscFn(torch.autograd.Function):
             elif n_lo:
                 dx[:n_lo].zero_()
         return (None, None, None, None, dx, *grads)
+
+
+def _multi(calls):
+    """Launches of one layer level: those that share a shape class (the period discriminators) side by side, the rest alone."""
+    if not calls:
+        return []
+    outs = [None] * len(calls)
+    classes = {}
+    for i, (x, w, kw) in enumerate(calls):
+        classes.setdefault((tuple(w.shape), x.size(2), kw.get("stride", 1), kw.get("in_div", 1), kw.get("groups", 1), x.dtype), []).append(i)
+    for idx in classes.values():
+        for lo in range(0, len(idx), 8):
+            part = idx[lo:lo + 8]
+            ys = K.conv1d_cl_multi([calls[i] for i in part]) if len(part) > 1 else [K.conv1d_cl_raw(calls[part[0]][0], calls[part[0]][1], **calls[part[0]][2])]
+            for i, y in zip(part, ys):
+                outs[i] = y
+    return outs
 
 
 def _f32(b):

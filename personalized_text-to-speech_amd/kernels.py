@@ -333,10 +333,9 @@ def _rows(t, name):
     return t.stride(1)
 
 
-def conv1d_cl_raw(x, w, bias=None, bias_b=None, res=None, mg_src=None, out=None, lengths=None, dil=1, pad=0, stride=1,
-                  in_slope=1.0, mg_slope=1.0, out_scale=1.0, flags=0, gate_h=0, out2=None, out_slope=None, in_div=1, t_out=None, groups=1):
-    """Launch vits_conv1d_cl.  x [b,t,c_in], w [k,c_out,c_in] (tap-major) in the same dtype; see
-    include/vitsmi.h for the fused prologue/epilogue.  Returns y (allocated unless `out` is given)."""
+def _conv_desc(x, w, bias=None, bias_b=None, res=None, mg_src=None, out=None, lengths=None, dil=1, pad=0, stride=1,
+               in_slope=1.0, mg_slope=1.0, out_scale=1.0, flags=0, gate_h=0, out2=None, out_slope=None, in_div=1, t_out=None, groups=1):
+    """-> (vits_conv_desc, y, (FLOP, algorithmic bytes), shape tag) of one vits_conv1d_cl launch; y is allocated unless `out` is given."""
     _lib.require_cuda(x, w)
     assert x.dtype == w.dtype
     b, t, c_in = x.shape
@@ -375,16 +374,49 @@ def conv1d_cl_raw(x, w, bias=None, bias_b=None, res=None, mg_src=None, out=None,
                       in_slope=float(in_slope), mg_slope=float(mg_slope), out_scale=float(out_scale), out_slope=float(out_slope or 0.0),
                       x=x.data_ptr(), w=w.data_ptr(), bias=p(bias), bias_b=p(bias_b), res=p(res), mg_src=p(mg_src),
                       y=out.data_ptr(), y2=p(out2), lengths=p(lengths))
+    es = x.element_size()                                      # units = (FLOP, algorithmic bytes: x + y + w read/written once)
+    units = (2.0 * b * t_out * c_out * (c_in // groups) * k,
+             es * (b * t * c_in + b * t_out * out.size(2) + k * c_out * c_in + (0 if res is None else res.numel())))
+    return d, out, units, f"b{b} t{t} ci{c_in} co{c_out} k{k} d{dil} s{stride}/{in_div} f{flags} {str(x.dtype)[6:]}"
+
+
+def conv1d_cl_raw(x, w, *args, **kw):
+    """Launch vits_conv1d_cl.  x [b,t,c_in], w [k,c_out,c_in] (tap-major) in the same dtype; see
+    include/vitsmi.h for the fused prologue/epilogue (keywords: _conv_desc).  Returns y (allocated unless `out` is given)."""
     import ctypes
+    d, out, units, shape = _conv_desc(x, w, *args, **kw)
     e0 = _lib.timer.start("vits_conv1d_cl")
     rc = _lib.lib().vits_conv1d_cl(ctypes.addressof(d), _lib.stream_ptr())
-    if e0 is not None:                                         # units = (FLOP, algorithmic bytes: x + y + w read/written once)
-        es = x.element_size()
-        _lib.timer.stop("vits_conv1d_cl", e0, (2.0 * b * t_out * c_out * (c_in // groups) * k,
-                                                es * (b * t * c_in + b * t_out * out.size(2) + k * c_out * c_in + (0 if res is None else res.numel()))),
-                        shape=f"b{b} t{t} ci{c_in} co{c_out} k{k} d{dil} s{stride}/{in_div} f{flags} {str(x.dtype)[6:]}")
+    _lib.timer.stop("vits_conv1d_cl", e0, units, shape=shape)
     _lib.check(rc, "vits_conv1d_cl")
     return out
+
+
+MULTI_LAUNCH = os.environ.get("VITS_NO_MULTI", "0") == "0"        # (measurement switch: off = always one launch per call)
+
+
+def conv1d_cl_multi(calls):
+    """Several independent vits_conv1d_cl launches — calls[i] = (x, w, keywords of conv1d_cl_raw) — as ONE launch where the
+    library can place them side by side (vits_conv1d_cl_multi: the same layer of the period discriminators), else one after
+    the other.  Returns the list of outputs; bitwise the results of the separate calls either way."""
+    import ctypes
+    built = [_conv_desc(x, w, **kw) for x, w, kw in calls]
+    n = len(built)
+    L, s = _lib.lib(), _lib.stream_ptr()
+    if MULTI_LAUNCH and 2 <= n <= 8:
+        arr = (_lib.ConvDesc * n)(*[b[0] for b in built])
+        e0 = _lib.timer.start("vits_conv1d_cl")
+        rc = L.vits_conv1d_cl_multi(ctypes.addressof(arr), n, s)
+        if rc != _lib.E_UNSUPPORTED:
+            _lib.timer.stop("vits_conv1d_cl", e0, tuple(sum(u) for u in zip(*[b[2] for b in built])), shape=f"multi x{n}: {built[0][3]}")
+            _lib.check(rc, "vits_conv1d_cl_multi")
+            return [b[1] for b in built]
+    for d, out, units, shape in built:
+        e0 = _lib.timer.start("vits_conv1d_cl")
+        rc = L.vits_conv1d_cl(ctypes.addressof(d), s)
+        _lib.timer.stop("vits_conv1d_cl", e0, units, shape=shape)
+        _lib.check(rc, "vits_conv1d_cl")
+    return [b[1] for b in built]
 
 
 class WnPacked:

@@ -407,6 +407,13 @@ def wn_layer_bwd(d_h, d_o, pre, packed, layer, lengths, dil, last, d_pre, d_h_ou
     return True
 
 
+def conv1d_cl_multi(calls):
+    """vits_conv1d_cl_multi: the calls one after the other (through whatever conv1d_cl_raw the package currently has)."""
+    import importlib
+    K = importlib.import_module("personalized_text-to-speech_amd.kernels")
+    return [K.conv1d_cl_raw(x, w, **kw) for x, w, kw in calls]
+
+
 def conv1d_cl_wgrad_batch(entries, defer=None):
     """vits_conv1d_cl_wgrad_batch: every entry is an ordinary weight (+ bias) gradient."""
     for e in entries:
@@ -418,6 +425,7 @@ def conv1d_cl_wgrad_batch(entries, defer=None):
 def install_rowops(monkeypatch):
     import importlib
     monkeypatch.setattr(importlib.import_module("personalized_text-to-speech_amd.kernels"), "conv1d_cl_wgrad_batch", conv1d_cl_wgrad_batch)
+    monkeypatch.setattr(importlib.import_module("personalized_text-to-speech_amd.kernels"), "conv1d_cl_multi", conv1d_cl_multi)
     monkeypatch.setattr(importlib.import_module("personalized_text-to-speech_amd.kernels"), "wn_layer_fwd", wn_layer_fwd)
     monkeypatch.setattr(importlib.import_module("personalized_text-to-speech_amd.kernels"), "WnPacked", WnPacked)
     monkeypatch.setattr(importlib.import_module("personalized_text-to-speech_amd.kernels"), "wn_layer_bwd", wn_layer_bwd)

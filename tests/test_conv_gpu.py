@@ -440,3 +440,53 @@ def test_grouped_direct_kernels_match_torch(pkg, case):
     D.grouped_wgrad(x, dy, k, stride, pad, groups, out2, db2, defer)
     defer.flush()
     assert torch.equal(out, out2) and torch.equal(db, db2)
+
+
+def test_multi_launch_is_bitwise_the_separate_launches(pkg):
+    """vits_conv1d_cl_multi (several problems of one kernel instance side by side: the same layer of the period discriminators,
+    models.py:299-335) against one vits_conv1d_cl per problem: forward (strided, bias, leaky-relu out) and the strided data
+    gradient (residual + lrelu' multiplier), different row counts and weights per problem; and a mixed batch that the library
+    must refuse as a whole (kernels.conv1d_cl_multi then launches one by one: same results)."""
+    K = pkg.kernels
+    torch.manual_seed(5)
+    dt = torch.bfloat16
+    geo = [(64, 152), (96, 102), (160, 61), (224, 44), (352, 28)]          # (items, rows per item) of the 512 -> 1024 layer's inputs
+    calls_f, calls_b = [], []
+    for b, t in geo:
+        x = torch.randn(b, t, 512, device=DEV).to(dt)
+        w = (torch.randn(5, 1024, 512, device=DEV) / 50).to(dt)
+        bias = torch.randn(1024, device=DEV)
+        calls_f.append((x, w, dict(bias=bias, pad=2, stride=3, out_slope=0.1)))
+        t_out = (t + 4 - 5) // 3 + 1
+        dy = torch.randn(b, t_out, 1024, device=DEV).to(dt)
+        wt = (torch.randn(5, 512, 1024, device=DEV) / 70).to(dt)
+        res = torch.randn(b, t, 512, device=DEV).to(dt)
+        calls_b.append((dy, wt, dict(res=res, mg_src=x, mg_slope=0.1, pad=2, in_div=3, t_out=t)))
+    for calls in (calls_f, calls_b):
+        was, K.MULTI_LAUNCH = K.MULTI_LAUNCH, True
+        try:
+            P = pkg._lib
+            n0 = P.timer.enabled
+            ys = K.conv1d_cl_multi(calls)
+        finally:
+            K.MULTI_LAUNCH = was
+        refs = [K.conv1d_cl_raw(x, w, **kw) for x, w, kw in calls]
+        for y, r in zip(ys, refs):
+            assert torch.equal(y, r)
+    # the library takes the five problems as ONE launch (not the fall-back)
+    import ctypes
+    built = [K._conv_desc(x, w, **kw) for x, w, kw in calls_f]
+    arr = (pkg._lib.ConvDesc * 5)(*[b[0] for b in built])
+    assert pkg._lib.lib().vits_conv1d_cl_multi(ctypes.addressof(arr), 5, pkg._lib.stream_ptr()) == 0
+    torch.cuda.synchronize()
+    # a batch with a problem of another class is refused as a whole ...
+    x = torch.randn(4, 100, 32, device=DEV).to(dt)
+    w = (torch.randn(5, 128, 32, device=DEV) / 10).to(dt)
+    mixed = calls_f[:2] + [(x, w, dict(pad=2, stride=3, out_slope=0.1))]
+    built = [K._conv_desc(a, b, **kw) for a, b, kw in mixed]
+    arr = (pkg._lib.ConvDesc * 3)(*[b[0] for b in built])
+    assert pkg._lib.lib().vits_conv1d_cl_multi(ctypes.addressof(arr), 3, pkg._lib.stream_ptr()) == pkg._lib.E_UNSUPPORTED
+    # ... and the Python entry then launches one by one
+    ys = K.conv1d_cl_multi(mixed)
+    for y, (a, b, kw) in zip(ys, mixed):
+        assert torch.equal(y, K.conv1d_cl_raw(a, b, **kw))

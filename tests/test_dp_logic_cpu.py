@@ -18,6 +18,7 @@ def emulated(pkg, monkeypatch):
     monkeypatch.setattr(pkg.kernels, "colsum", cl_emul.colsum)
     monkeypatch.setattr(pkg.kernels, "conv1d_cl_wgrad_raw", cl_emul.conv1d_cl_wgrad_raw)
     monkeypatch.setattr(pkg.kernels, "conv1d_cl_wgrad_batch", cl_emul.conv1d_cl_wgrad_batch)
+    monkeypatch.setattr(pkg.kernels, "conv1d_cl_multi", cl_emul.conv1d_cl_multi)
     cl_emul.install_rowops(monkeypatch)
     return pkg
 
