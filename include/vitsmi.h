@@ -65,6 +65,12 @@ int vits_mas_f32(const float* neg_cent, void* path, int path_dtype,
                  const int32_t* t_ys, const int32_t* t_xs,
                  int b, int t_t, int t_s, int32_t* status, void* stream);
 
+/* The host twin of vits_mas_f32: the same contract on HOST pointers, no stream (the reference's FFI,
+ * monotonic_align/core.pyx:36-42, is a host routine).  An entry point for callers that hold host buffers and for checking the
+ * device kernel without a GPU — this package's own path never calls it (its Python operators raise on host tensors). */
+int vits_mas_f32_cpu(const float* neg_cent, void* path, int path_dtype, const int32_t* t_ys, const int32_t* t_xs,
+                     int b, int t_t, int t_s, int32_t* status);
+
 /* ------------------------------------------------------------------------------------------
  * Channels-last 1-D convolution, stride 1, on the matrix cores (forward and data gradient).
  *

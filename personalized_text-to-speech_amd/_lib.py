@@ -50,6 +50,7 @@ SIGNATURES = {
     "vits_wgrad_reduce_pending": (c_int, [c_void_p, c_int, c_void_p]),
     "vits_conv1d_cl_wgrad_batch_plan": (c_int, [c_void_p, c_int, c_void_p]),
     "vits_conv1d_cl_wgrad_batch": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "vits_mas_f32_cpu": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "vits_conv1d_cl": (c_int, [c_void_p, c_void_p]),
     "vits_conv1d_cl_multi": (c_int, [c_void_p, c_int, c_void_p]),
     "vits_wn_layer_fwd": (c_int, [c_void_p, c_void_p]),
