@@ -443,7 +443,8 @@ int conv1d_ring_multi_dispatch(const vits_conv_desc* d, const int* t_out, int co
     const int rc = ring_plan(d[i], t_out[i], &p);
     if (rc != VITS_OK) return rc;
     if (i == 0) p0 = p;
-    else if (p.BM != p0.BM || p.wide != p0.wide) return VITS_E_UNSUPPORTED;
+    else if (p.BM != p0.BM) return VITS_E_UNSUPPORTED;
+    if (p.wide) p0.wide = true;          // (the wide instance also runs the narrow problems: its extra X slots stay empty)
     lds = p.lds > lds ? p.lds : lds;
     m.a[i] = p.args;
     m.start[i] = start;

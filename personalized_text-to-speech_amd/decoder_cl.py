@@ -116,36 +116,55 @@ class DecoderFn(torch.autograd.Function):
             x = convt_fold(p, w[iu[1]], c_out, k, u, pad)
             saved.append(h)
             xs = torch.empty_like(x)
-            for j in range(plan.num_kernels):
-                ch, rk, dils = plan.res[ri]
-                ri += 1
-                r = x
-                units = []
-                for l, d in enumerate(dils):
-                    last = l == len(dils) - 1
-                    if plan.resblock1:
-                        i1, i2 = (next(it), next(it)), (next(it), next(it))
-                        t1 = C(r, w[i1[0]], w[i1[1]], dil=d, pad=(rk * d - d) // 2, in_slope=0.1)
-                        if last:
-                            C(t1, w[i2[0]], w[i2[1]], res=r, out=xs, pad=(rk - 1) // 2, in_slope=0.1,
-                              out_scale=1.0 / plan.num_kernels, flags=K.CONV_ACCUM if j > 0 else 0)
-                            r_new = None
-                        else:
-                            r_new = C(t1, w[i2[0]], w[i2[1]], res=r, pad=(rk - 1) // 2, in_slope=0.1)
-                        units.append((i1, i2, d))
-                        saved += [r, t1]
+            # weight slots in module order (resblock by resblock, unit by unit) ...
+            nk, stage = plan.num_kernels, plan.res[ri:ri + plan.num_kernels]
+            slots = []
+            for j in range(nk):
+                per = []
+                for _ in stage[j][2]:
+                    i1 = (next(it), next(it))
+                    per.append((i1, (next(it), next(it)) if plan.resblock1 else None))
+                slots.append(per)
+            ri += nk
+            # ... but the launches go unit by unit ACROSS the parallel resblocks: the k = 3 / 7 / 11 resblocks of a stage read the
+            # same x and are independent until their sum — at the first stage each of their convolutions alone is half a
+            # round of workgroups, side by side (K.conv1d_cl_multi) they share the chip and the launch boundary.  The last
+            # convolution of each resblock accumulates into the shared sum and stays one launch after the other.
+            nd = len(stage[0][2])
+            assert all(len(st[2]) == nd for st in stage)
+            r = [x] * nk
+            rec = [[None] * nd for _ in range(nk)]
+            for l in range(nd):
+                last = l == nd - 1
+                geo = [(stage[j][1], stage[j][2][l]) for j in range(nk)]                      # (kernel size, dilation)
+                if plan.resblock1:
+                    t1s = K.conv1d_cl_multi([(r[j], w[slots[j][l][0][0]], dict(bias=w[slots[j][l][0][1]], dil=d, pad=(rk * d - d) // 2, in_slope=0.1))
+                                             for j, (rk, d) in enumerate(geo)])
+                    for j in range(nk):
+                        rec[j][l] = (r[j], t1s[j])
+                    if last:
+                        for j, (rk, d) in enumerate(geo):
+                            i2 = slots[j][l][1]
+                            C(t1s[j], w[i2[0]], w[i2[1]], res=r[j], out=xs, pad=(rk - 1) // 2, in_slope=0.1,
+                              out_scale=1.0 / nk, flags=K.CONV_ACCUM if j > 0 else 0)
                     else:
-                        i1 = (next(it), next(it))
-                        if last:
-                            C(r, w[i1[0]], w[i1[1]], res=r, out=xs, dil=d, pad=(rk * d - d) // 2, in_slope=0.1,
-                              out_scale=1.0 / plan.num_kernels, flags=K.CONV_ACCUM if j > 0 else 0)
-                            r_new = None
-                        else:
-                            r_new = C(r, w[i1[0]], w[i1[1]], res=r, dil=d, pad=(rk * d - d) // 2, in_slope=0.1)
-                        units.append((i1, None, d))
-                        saved.append(r)
-                    r = r_new
-                idx["res"].append(units)
+                        r = K.conv1d_cl_multi([(t1s[j], w[slots[j][l][1][0]], dict(bias=w[slots[j][l][1][1]], res=r[j], pad=(rk - 1) // 2, in_slope=0.1))
+                                               for j, (rk, d) in enumerate(geo)])
+                else:
+                    for j in range(nk):
+                        rec[j][l] = (r[j],)
+                    if last:
+                        for j, (rk, d) in enumerate(geo):
+                            i1 = slots[j][l][0]
+                            C(r[j], w[i1[0]], w[i1[1]], res=r[j], out=xs, dil=d, pad=(rk * d - d) // 2, in_slope=0.1,
+                              out_scale=1.0 / nk, flags=K.CONV_ACCUM if j > 0 else 0)
+                    else:
+                        r = K.conv1d_cl_multi([(r[j], w[slots[j][l][0][0]], dict(bias=w[slots[j][l][0][1]], res=r[j], dil=d, pad=(rk * d - d) // 2, in_slope=0.1))
+                                               for j, (rk, d) in enumerate(geo)])
+            for j in range(nk):                                   # (saved in module order: the backward pops it in reverse)
+                idx["res"].append([(slots[j][l][0], slots[j][l][1], stage[j][2][l]) for l in range(nd)])
+                for l in range(nd):
+                    saved += list(rec[j][l])
             h = xs
         i_post = next(it)
         y = C(h, w[i_post], None, pad=3, in_slope=0.01, flags=K.CONV_TANH)
@@ -196,35 +215,41 @@ class DecoderFn(torch.autograd.Function):
             c_in, c_out, k, u, pad = plan.ups[s]
             dxs = dh * (1.0 / plan.num_kernels)
             dx = torch.empty_like(dxs)
-            for j in reversed(range(plan.num_kernels)):
-                ri -= 1
-                ch, rk, dils = plan.res[ri]
-                units = idx["res"][ri]
-                dr = dxs
-                for l in reversed(range(len(dils))):
-                    i1, i2, d = units[l]
-                    first = l == 0
+            nk = plan.num_kernels
+            ri -= nk
+            stage, units = plan.res[ri:ri + nk], idx["res"][ri:ri + nk]
+            nd = len(stage[0][2])
+            rec = [[None] * nd for _ in range(nk)]                 # saved in module order: pop resblocks and units in reverse
+            for j in reversed(range(nk)):
+                for l in reversed(range(nd)):
                     if plan.resblock1:
                         t1 = saved.pop()
-                        r_in = saved.pop()
-                        p2, p1 = (rk - 1) // 2, (rk * d - d) // 2
-                        grads[i2[0]] = WGo(t1, dr, rk, i2[0], i2[1], pad=p2, in_slope=0.1)
-                        dt1 = C(dr, flip_t(i2[0]), None, mg_src=t1, pad=p2, mg_slope=0.1)
-                        grads[i1[0]] = WGo(r_in, dt1, rk, i1[0], i1[1], dil=d, pad=p1, in_slope=0.1)
-                        if first:     # gradient wrt the stage input x: accumulated over the parallel resblocks
-                            _dgrad_res(dt1, flip_t(i1[0]), r_in, dr, d, p1, out=dx, accum=j < plan.num_kernels - 1)
-                            dr = None
-                        else:
-                            dr = _dgrad_res(dt1, flip_t(i1[0]), r_in, dr, d, p1)
+                        rec[j][l] = (saved.pop(), t1)
                     else:
-                        r_in = saved.pop()
-                        p1 = (rk * d - d) // 2
-                        grads[i1[0]] = WGo(r_in, dr, rk, i1[0], i1[1], dil=d, pad=p1, in_slope=0.1)
-                        if first:
-                            _dgrad_res(dr, flip_t(i1[0]), r_in, dr, d, p1, out=dx, accum=j < plan.num_kernels - 1)
-                            dr = None
-                        else:
-                            dr = _dgrad_res(dr, flip_t(i1[0]), r_in, dr, d, p1)
+                        rec[j][l] = (saved.pop(),)
+            dr = [dxs] * nk
+            for l in reversed(range(nd)):                          # unit by unit across the parallel resblocks (see forward)
+                first = l == 0
+                geo = [(stage[j][1], units[j][l][2]) for j in range(nk)]
+                if plan.resblock1:
+                    for j, (rk, d) in enumerate(geo):
+                        i2 = units[j][l][1]
+                        grads[i2[0]] = WGo(rec[j][l][1], dr[j], rk, i2[0], i2[1], pad=(rk - 1) // 2, in_slope=0.1)
+                    dt1 = K.conv1d_cl_multi([(dr[j], flip_t(units[j][l][1][0]), dict(mg_src=rec[j][l][1], pad=(rk - 1) // 2, mg_slope=0.1))
+                                             for j, (rk, d) in enumerate(geo)])
+                else:
+                    dt1 = dr
+                for j, (rk, d) in enumerate(geo):
+                    i1 = units[j][l][0]
+                    grads[i1[0]] = WGo(rec[j][l][0], dt1[j], rk, i1[0], i1[1], dil=d, pad=(rk * d - d) // 2, in_slope=0.1)
+                if first:      # gradient wrt the stage input x: accumulated over the parallel resblocks, one launch after the other
+                    for j in reversed(range(nk)):
+                        rk, d = geo[j]
+                        _dgrad_res(dt1[j], flip_t(units[j][l][0][0]), rec[j][l][0], dr[j], d, (rk * d - d) // 2, out=dx, accum=j < nk - 1)
+                else:
+                    dr = K.conv1d_cl_multi([(dt1[j], flip_t(units[j][l][0][0]),
+                                             dict(res=dr[j], mg_src=rec[j][l][0], dil=d, pad=(rk * d - d) // 2, mg_slope=0.1, flags=K.CONV_RES_AFTER))
+                                            for j, (rk, d) in enumerate(geo)])
             # upsampler: x = fold(conv1x1(lrelu(h_prev)))
             h_prev = saved.pop()
             iu = idx["ups"][s]
