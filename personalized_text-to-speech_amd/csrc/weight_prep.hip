@@ -148,7 +148,9 @@ __global__ __launch_bounds__(256) void prep_bwd(const vits_prep_entry* __restric
   };
   // (Measured and not kept: the passes tap-major — scattered dv writes, 1.7x slower; the row of dW staged in LDS by 16-byte
   // tap-plane loads — 265 against 228 us per launch, the 24 KB per workgroup cost more occupancy than the gathers cost; the
-  // thread's elements of v and dW kept in registers between the passes, one trip to memory — no change in an A/B of the step.)
+  // thread's elements of v and dW kept in registers between the passes, one trip to memory — no change in an A/B of the step;
+  // one WAVE per row, four rows per workgroup, butterfly reductions without LDS or barriers — 255 us.  What is left is the
+  // gather itself: a wave's 64 consecutive parameter elements lie in k tap planes of dW, 5-10 cache lines per load.)
   if (!e.g) {
     for (int i = threadIdx.x; i < inner; i += blockDim.x) dv[i] = dw_at(i);
     return;
