@@ -196,7 +196,7 @@ def main():
     os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--branches", default=None, help="comma list of side-stream branches (enc_p,dp,mel); default: all")
+    ap.add_argument("--branches", default=None, help="comma list of side-stream branches (enc_p,dp,prior,mel); default: enc_p,dp,prior")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="C2")

@@ -462,7 +462,7 @@ class SynthesizerTrn(nn.Module):
         self.resblock, self.resblock_kernel_sizes, self.resblock_dilation_sizes = resblock, resblock_kernel_sizes, resblock_dilation_sizes
         self.upsample_rates, self.upsample_initial_channel, self.upsample_kernel_sizes = upsample_rates, upsample_initial_channel, upsample_kernel_sizes
         self.segment_size, self.n_speakers, self.gin_channels, self.use_sdp = segment_size, n_speakers, gin_channels, use_sdp
-        self.side_branches = {"enc_p", "dp"}      # training forward: sub-graphs that run as side-stream branches (kernels.SideBranch)
+        self.side_branches = {"enc_p", "dp", "prior"}      # training forward: sub-graphs that run as side-stream branches (kernels.SideBranch)
 
         self.enc_p = TextEncoder(n_vocab, inter_channels, hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout)
         self.dec = Generator(inter_channels, resblock, resblock_kernel_sizes, resblock_dilation_sizes, upsample_rates,
@@ -569,6 +569,8 @@ class SynthesizerTrn(nn.Module):
         g = self._speaker(sid)
         z, m_q, logs_q, y_mask = self.enc_q(y, y_lengths, g=g)
         z_p = self.flow(z, y_mask, g=g)
+        if enc_branch is not None and "prior" in self.side_branches and "dp" in self.side_branches:
+            return self._forward_prior_on_lane(x, m_p, logs_p, x_mask, z, z_p, m_q, logs_q, y_mask, y_lengths, g)
         if enc_branch is not None:
             x, m_p, logs_p, x_mask = enc_branch.join(x, m_p, logs_p, x_mask)
 
@@ -604,6 +606,31 @@ class SynthesizerTrn(nn.Module):
         if branch is not None:
             l_length = branch.join(l_length)
         l_length = l_length / torch.sum(x_mask)
+        return o, l_length, attn, ids_slice, x_mask, y_mask, (z, z_p, m_p, logs_p, m_q, logs_q)
+
+    def _forward_prior_on_lane(self, x, m_p, logs_p, x_mask, z, z_p, m_q, logs_q, y_mask, y_lengths, g):
+        """The rest of _forward with everything between the flow and the losses that is NOT the decoder — alignment scores,
+        the alignment search (16 workgroups for ~100 us), the duration predictor, the expansion of the prior — on the side
+        stream the text encoder ran on (its results never leave that stream), next to the decoder on the main one."""
+        prior = K.SideBranch(z_p.device, z_p, y_mask, g)
+        with prior:
+            with torch.no_grad():
+                neg_cent = self.neg_cent(z_p, m_p, logs_p)
+                attn_mask = torch.unsqueeze(x_mask, 2) * torch.unsqueeze(y_mask, -1)
+                attn = K.maximum_path(neg_cent, attn_mask.squeeze(1)).unsqueeze(1).detach().to(x.dtype)
+            w = attn.sum(2)
+            if self.use_sdp:
+                l_length = self.dp(x, x_mask, w, g=g)
+            else:
+                logw_ = torch.log(w + 1e-6) * x_mask
+                logw = self.dp(x, x_mask, g=g)
+                l_length = commons.sum12((logw - logw_) ** 2)
+            l_length = l_length / torch.sum(x_mask)
+            m_p = torch.matmul(attn.squeeze(1), m_p.transpose(1, 2)).transpose(1, 2)
+            logs_p = torch.matmul(attn.squeeze(1), logs_p.transpose(1, 2)).transpose(1, 2)
+        z_slice, ids_slice = commons.rand_slice_segments(z, y_lengths, self.segment_size)
+        o = self.dec(z_slice, g=g)
+        l_length, attn, m_p, logs_p, x_mask = prior.join(l_length, attn, m_p, logs_p, x_mask)
         return o, l_length, attn, ids_slice, x_mask, y_mask, (z, z_p, m_p, logs_p, m_q, logs_q)
 
     def _infer(self, x, x_lengths, sid=None, noise_scale=1, length_scale=1, noise_scale_w=1.0, max_len=None, durations=None):

@@ -50,7 +50,9 @@ class FineTuner:
         # flow, "dp" = the stochastic duration predictor next to the decoder / discriminators, forward and backward
         # (34.5 -> 27.3 ms/step together; replays bitwise reproducible — DESIGN.md §6b tells how the "dp" branch exposed the
         # spline kernel's irreproducibility under concurrency and what cured it).  Also available, off: "mel" (slower).
-        self.side_branches = frozenset(("enc_p", "dp"))
+        # "prior" (with both of the above): alignment scores, alignment search and the expansion of the prior join the duration
+        # predictor on the side stream, next to the decoder (19.85 -> 19.67 ms/step, A/B on one box).
+        self.side_branches = frozenset(("enc_p", "dp", "prior"))
         # One stream for everything that is ever captured (warm-up steps, captures, the bucket hooks' registration): autograd
         # runs a parameter's AccumulateGrad on the stream that was current when that node was CREATED and a post-accumulate
         # hook pins the node, and a capture must not have to synchronise with the legacy default stream (step_padded).

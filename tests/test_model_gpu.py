@@ -146,7 +146,8 @@ def test_captured_step_replays_reproducibly(pkg):
     hps = cfgs.get("modified_finetune_speaker")
     ft = tr.FineTuner(hps, "cuda:0", amp=True)
     batch = tr.synthetic_batch(hps, 4, (100, 160), "cuda:0")
-    assert ft.side_branches == {"enc_p", "dp"}       # text encoder and duration predictor as side-stream branches of the graph
+    # text encoder, duration predictor and (between them, on the same stream) alignment + prior expansion as side-stream branches
+    assert ft.side_branches == {"enc_p", "dp", "prior"}
     ft.capture(batch, warmup=2)
     for _ in range(3):                                # a race between branches would be intermittent
         losses = ft.verify_replay()
